@@ -1,0 +1,84 @@
+"""ctypes binding of libadf_wls.so (the C-ABI of include/adf_wls.h).
+
+The product path has no CPU fallback: if the HIP library is missing or fails to
+load, importing the filter API raises.  Nothing here touches oracle/.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libadf_wls.so")
+
+ADF_OK, ADF_EBADARG, ADF_ESIZE, ADF_EHIP, ADF_ENOMEM, ADF_ENODEV = range(6)
+SOLVER_EXACT, SOLVER_WAVE = 0, 1
+DEPTH_8U, DEPTH_16S, DEPTH_32F = 0, 3, 5
+
+
+class AdfError(RuntimeError):
+    """Counterpart of cv::Exception raised by CV_Assert / CV_Error on the reference path."""
+
+    def __init__(self, code, msg):
+        super().__init__("adf error %d: %s" % (code, msg))
+        self.code = code
+
+
+class Rect(C.Structure):
+    _fields_ = [("x", C.c_int), ("y", C.c_int), ("width", C.c_int), ("height", C.c_int)]
+
+
+# every symbol include/adf_wls.h declares: (name, restype, argtypes)
+_vp, _i, _d, _pd, _sz = C.c_void_p, C.c_int, C.c_double, C.c_ssize_t, C.c_size_t
+_FILTER_DEV = [_vp, _i, _vp, _pd, _pd, _vp, _pd, _pd, _i, _i, _i, _vp, _pd, _pd, _vp, _pd, _pd,
+               C.POINTER(Rect), _vp]
+SYMBOLS = [
+    ("adf_version", _i, []),
+    ("adf_last_error", C.c_char_p, []),
+    ("adf_device_count", _i, []),
+    ("adf_wls_create", _i, [C.POINTER(_vp), _i, _i, _i, _i, _i, _i]),
+    ("adf_wls_destroy", None, [_vp]),
+    ("adf_wls_set_lambda", _i, [_vp, _d]),
+    ("adf_wls_get_lambda", _i, [_vp, C.POINTER(_d)]),
+    ("adf_wls_set_sigma_color", _i, [_vp, _d]),
+    ("adf_wls_get_sigma_color", _i, [_vp, C.POINTER(_d)]),
+    ("adf_wls_set_lrc_thresh", _i, [_vp, _i]),
+    ("adf_wls_get_lrc_thresh", _i, [_vp, C.POINTER(_i)]),
+    ("adf_wls_set_depth_discontinuity_radius", _i, [_vp, _i]),
+    ("adf_wls_get_depth_discontinuity_radius", _i, [_vp, C.POINTER(_i)]),
+    ("adf_wls_set_fgs_params", _i, [_vp, _d, _i]),
+    ("adf_wls_set_solver", _i, [_vp, _i]),
+    ("adf_wls_get_solver", _i, [_vp, C.POINTER(_i)]),
+    ("adf_wls_filter_device", _i, _FILTER_DEV),
+    ("adf_wls_filter_host", _i, _FILTER_DEV[:-1]),
+    ("adf_wls_get_confidence_device", _i, [_vp, _i, _vp, _pd, _vp]),
+    ("adf_wls_get_confidence_host", _i, [_vp, _i, _vp, _pd]),
+    ("adf_wls_get_roi", _i, [_vp, C.POINTER(Rect)]),
+    ("adf_wls_sync", _i, [_vp, _vp]),
+    ("adf_wls_workspace_bytes", _sz, [_vp]),
+    ("adf_fgs_create", _i, [C.POINTER(_vp), _vp, _pd, _i, _i, _i, _d, _d, _d, _i, _i]),
+    ("adf_fgs_destroy", None, [_vp]),
+    ("adf_fgs_filter_host", _i, [_vp, _vp, _pd, _vp, _pd, _i, _i]),
+]
+
+_lib = None
+
+
+def lib():
+    """Load the HIP library; raise loudly if it is not built (no fallback exists)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(
+                "%s is missing: build the HIP extension first "
+                "(python -c 'import __graft_entry__ as g; g.build()')" % LIB_PATH)
+        L = C.CDLL(LIB_PATH)
+        for name, res, args in SYMBOLS:
+            fn = getattr(L, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = L
+    return _lib
+
+
+def check(rc):
+    if rc != ADF_OK:
+        raise AdfError(rc, lib().adf_last_error().decode("utf-8", "replace"))

@@ -1,0 +1,524 @@
+// adf_api.hip -- host side of the C-ABI declared in include/adf_wls.h.
+//
+// Orchestrates DisparityWLSFilterImpl::filter (DF.cpp:219-298) and
+// FastGlobalSmootherFilterImpl::{init,filter} (FGS.cpp:141-233) as a fixed sequence of HIP kernel
+// launches on the caller's stream.  No host<->device synchronisation happens on the device-pointer
+// path after the workspace exists, so a caller may capture it into a hipGraph.
+#include "adf_internal.h"
+#include "../../include/adf_wls.h"
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <new>
+#include <vector>
+
+using namespace adf;
+
+// ----------------------------------------------------------------------------------------------
+// error plumbing
+// ----------------------------------------------------------------------------------------------
+static thread_local char g_err[512] = "";
+
+static int fail(int code, const char* fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                         \
+    do {                                                                                      \
+        hipError_t e_ = (expr);                                                               \
+        if (e_ != hipSuccess)                                                                 \
+            return fail(e_ == hipErrorOutOfMemory ? ADF_ENOMEM : ADF_EHIP, "%s failed: %s",   \
+                        #expr, hipGetErrorString(e_));                                        \
+    } while (0)
+
+extern "C" int adf_version(void) { return ADF_VERSION; }
+extern "C" const char* adf_last_error(void) { return g_err; }
+extern "C" int adf_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+// ----------------------------------------------------------------------------------------------
+// shared pieces
+// ----------------------------------------------------------------------------------------------
+static inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
+
+static Geom make_geom(int W, int H, int rx, int ry, int rw, int rh)
+{
+    Geom g;
+    g.W = W; g.H = H; g.rx = rx; g.ry = ry; g.rw = rw; g.rh = rh;
+    g.pw = round_up(rw, 64);
+    g.ph = round_up(rh, 64);
+    size_t a = (size_t)rh * g.pw, b = (size_t)rw * g.ph;
+    g.plane = ((a > b ? a : b) + 63) / 64 * 64;
+    g.frame = (size_t)W * H;
+    return g;
+}
+
+// RAII: run on the handle's device, restore the caller's on exit.
+struct DeviceScope {
+    int prev = -1; bool switched = false;
+    explicit DeviceScope(int dev)
+    {
+        if (hipGetDevice(&prev) == hipSuccess && prev != dev) switched = hipSetDevice(dev) == hipSuccess;
+    }
+    ~DeviceScope() { if (switched) hipSetDevice(prev); }
+};
+
+// Growable device buffer (never shrinks; freed with the handle).
+struct DevBuf {
+    void* p = nullptr; size_t bytes = 0;
+    int reserve(size_t need, hipStream_t st)
+    {
+        if (need <= bytes) return ADF_OK;
+        if (p) { HIP_TRY(hipStreamSynchronize(st)); HIP_TRY(hipFree(p)); p = nullptr; bytes = 0; }
+        need = (need + 255) / 256 * 256;
+        HIP_TRY(hipMalloc(&p, need));
+        bytes = need;
+        // deterministic padding lanes: the sweeps read (and discard) pitch padding
+        HIP_TRY(hipMemsetAsync(p, 0, need, st));
+        return ADF_OK;
+    }
+    void release() { if (p) hipFree(p); p = nullptr; bytes = 0; }
+};
+
+// Weight LUT (FGS.cpp:150-154, 663-675), built on the host with libm and cached per sigma.
+struct Lut {
+    DevBuf dev; float sigma = -1.0f; bool valid = false;
+    int ensure(float s, hipStream_t st)
+    {
+        if (valid && s == sigma) return ADF_OK;
+        std::vector<float> host(ADF_LUT_LEVELS);
+        for (int i = 0; i < ADF_LUT_LEVELS; i++) host[i] = -expf(-sqrtf((float)i) / s);
+        int rc = dev.reserve(sizeof(float) * ADF_LUT_LEVELS, st);
+        if (rc) return rc;
+        // synchronous copy: the pageable staging vector dies at scope exit
+        HIP_TRY(hipStreamSynchronize(st));
+        HIP_TRY(hipMemcpy(dev.p, host.data(), sizeof(float) * ADF_LUT_LEVELS, hipMemcpyHostToDevice));
+        sigma = s; valid = true;
+        return ADF_OK;
+    }
+};
+
+// The six (2*num_iter) solve passes of FGS.cpp:207-212 on planes already resident on the device.
+// `A` holds the right-hand sides in the orientation the first (horizontal) pass wants.
+struct SolvePlanes {
+    float* CH; float* CV;       // weights (orientation depends on the solver)
+    float* D; float* F0; float* F1;
+    float* A0; float* A1;       // ping
+    float* B0; float* B1;       // pong
+};
+
+struct FinalOut {
+    int epilogue; void* out; ptrdiff_t stride, pair_stride; int x0, y0, cn, c;
+};
+
+static int run_passes_exact(const Geom& g, const SolvePlanes& p, int n_rhs, float lambda, float atten,
+                            int num_iter, const FinalOut& fo, int n_pairs, hipStream_t st)
+{
+    float lam = lambda;
+    for (int it = 0; it < num_iter; it++) {
+        PassArgs h{};
+        h.C = p.CH; h.U0 = p.A0; h.U1 = p.A1; h.D = p.D; h.F0 = p.F0; h.F1 = p.F1;
+        h.O0 = p.B0; h.O1 = p.B1;
+        h.nscan = g.rh; h.len = g.rw; h.pitch_in = g.ph; h.pitch_out = g.pw;
+        h.plane = g.plane; h.lambda = lam;
+        HIP_TRY(launch_exact_pass(h, n_rhs, EPI_PLANES, n_pairs, st));   // FGS.cpp:209
+
+        const bool last = (it == num_iter - 1);
+        PassArgs v{};
+        v.C = p.CV; v.U0 = p.B0; v.U1 = p.B1; v.D = p.D; v.F0 = p.F0; v.F1 = p.F1;
+        v.O0 = p.A0; v.O1 = p.A1;
+        v.nscan = g.rw; v.len = g.rh; v.pitch_in = g.pw; v.pitch_out = g.ph;
+        v.plane = g.plane; v.lambda = lam;
+        if (last) {
+            v.out = fo.out; v.out_stride = fo.stride; v.out_pair_stride = fo.pair_stride;
+            v.out_x0 = fo.x0; v.out_y0 = fo.y0; v.out_cn = fo.cn; v.out_c = fo.c;
+        }
+        HIP_TRY(launch_exact_pass(v, n_rhs, last ? fo.epilogue : EPI_PLANES, n_pairs, st)); // FGS.cpp:210
+        lam *= atten;                                                      // FGS.cpp:211 (float)
+    }
+    return ADF_OK;
+}
+
+// ----------------------------------------------------------------------------------------------
+// DisparityWLSFilter
+// ----------------------------------------------------------------------------------------------
+struct adf_wls {
+    int device = 0;
+    // DF.cpp:142-159
+    int left_offset = 0, right_offset = 0, top_offset = 0, bottom_offset = 0;
+    int min_disp = 0;
+    bool use_confidence = true;
+    double lambda = 8000.0, sigma_color = 1.0;
+    int lrc_thresh = 24, disc_radius = 5;
+    float roll_off = 0.001f;
+    // EF.hpp:393 defaults used by DF.cpp:292
+    double atten = 0.25; int num_iter = 3;
+    int solver = ADF_SOLVER_EXACT;
+    // state of the last call
+    adf_rect roi{0, 0, 0, 0};
+    int last_W = 0, last_H = 0, last_pairs = 0;
+    // device memory
+    Lut lut;
+    DevBuf ws;    // per-chunk workspace
+    DevBuf conf;  // confidence maps of the last call (n_pairs full frames)
+    DevBuf stage; // host-pointer path staging
+    size_t ws_limit = (size_t)64 << 30;
+};
+
+extern "C" int adf_wls_create(adf_wls_t** out, int use_confidence, int l, int r, int t, int b, int min_disp)
+{
+    if (!out) return fail(ADF_EBADARG, "adf_wls_create: out is NULL");
+    *out = nullptr;
+    if (l < 0 || r < 0 || t < 0 || b < 0) return fail(ADF_EBADARG, "adf_wls_create: negative offset");
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0)
+        return fail(ADF_ENODEV, "adf_wls_create: no HIP device visible");
+    adf_wls* h = new (std::nothrow) adf_wls();
+    if (!h) return fail(ADF_ENOMEM, "adf_wls_create: out of host memory");
+    if (hipGetDevice(&h->device) != hipSuccess) { delete h; return fail(ADF_EHIP, "hipGetDevice failed"); }
+    h->use_confidence = use_confidence != 0;
+    h->left_offset = l; h->right_offset = r; h->top_offset = t; h->bottom_offset = b;
+    h->min_disp = 0; (void)min_disp; // DF.cpp:146 then :149
+    if (const char* e = getenv("ADF_WS_LIMIT_GB")) {
+        double gb = atof(e);
+        if (gb > 0) h->ws_limit = (size_t)(gb * (double)((size_t)1 << 30));
+    }
+    *out = h;
+    return ADF_OK;
+}
+
+extern "C" void adf_wls_destroy(adf_wls_t* h)
+{
+    if (!h) return;
+    DeviceScope ds(h->device);
+    h->lut.dev.release(); h->ws.release(); h->conf.release(); h->stage.release();
+    delete h;
+}
+
+#define NEED_HANDLE(h) do { if (!(h)) return fail(ADF_EBADARG, "%s: handle is NULL", __func__); } while (0)
+
+extern "C" int adf_wls_set_lambda(adf_wls_t* h, double v) { NEED_HANDLE(h); h->lambda = v; return ADF_OK; }
+extern "C" int adf_wls_get_lambda(const adf_wls_t* h, double* v) { NEED_HANDLE(h); if (v) *v = h->lambda; return ADF_OK; }
+extern "C" int adf_wls_set_sigma_color(adf_wls_t* h, double v) { NEED_HANDLE(h); h->sigma_color = v; return ADF_OK; }
+extern "C" int adf_wls_get_sigma_color(const adf_wls_t* h, double* v) { NEED_HANDLE(h); if (v) *v = h->sigma_color; return ADF_OK; }
+extern "C" int adf_wls_set_lrc_thresh(adf_wls_t* h, int v) { NEED_HANDLE(h); h->lrc_thresh = v; return ADF_OK; }
+extern "C" int adf_wls_get_lrc_thresh(const adf_wls_t* h, int* v) { NEED_HANDLE(h); if (v) *v = h->lrc_thresh; return ADF_OK; }
+extern "C" int adf_wls_set_depth_discontinuity_radius(adf_wls_t* h, int v) { NEED_HANDLE(h); h->disc_radius = v; return ADF_OK; }
+extern "C" int adf_wls_get_depth_discontinuity_radius(const adf_wls_t* h, int* v) { NEED_HANDLE(h); if (v) *v = h->disc_radius; return ADF_OK; }
+
+extern "C" int adf_wls_set_fgs_params(adf_wls_t* h, double atten, int num_iter)
+{
+    NEED_HANDLE(h);
+    if (num_iter < 1) return fail(ADF_EBADARG, "num_iter must be >= 1 (FGS.cpp:143)");
+    h->atten = atten; h->num_iter = num_iter;
+    return ADF_OK;
+}
+
+extern "C" int adf_wls_set_solver(adf_wls_t* h, int solver)
+{
+    NEED_HANDLE(h);
+    if (solver != ADF_SOLVER_EXACT) return fail(ADF_EBADARG, "solver %d not available in this build", solver);
+    h->solver = solver;
+    return ADF_OK;
+}
+extern "C" int adf_wls_get_solver(const adf_wls_t* h, int* v) { NEED_HANDLE(h); if (v) *v = h->solver; return ADF_OK; }
+
+extern "C" int adf_wls_get_roi(const adf_wls_t* h, adf_rect* roi) { NEED_HANDLE(h); if (roi) *roi = h->roi; return ADF_OK; }
+extern "C" size_t adf_wls_workspace_bytes(const adf_wls_t* h)
+{
+    return h ? h->ws.bytes + h->conf.bytes + h->stage.bytes + h->lut.dev.bytes : 0;
+}
+
+extern "C" int adf_wls_sync(adf_wls_t* h, void* stream)
+{
+    NEED_HANDLE(h);
+    DeviceScope ds(h->device);
+    HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+    return ADF_OK;
+}
+
+static size_t wls_pair_ws_bytes(const Geom& g, bool conf)
+{
+    // ROI planes: CH CV D F0 A0 B0 (+ F1 A1 B1 with confidence); full frames: cL cR
+    size_t planes = conf ? 9 : 6;
+    return planes * g.plane * sizeof(float) + (conf ? 2 * g.frame * sizeof(float) : 0);
+}
+
+extern "C" int adf_wls_filter_device(adf_wls_t* h, int n_pairs,
+                                     const int16_t* dispL, ptrdiff_t sL, ptrdiff_t psL,
+                                     const uint8_t* view, ptrdiff_t sG, ptrdiff_t psG, int gch, int W, int H,
+                                     int16_t* out, ptrdiff_t sO, ptrdiff_t psO,
+                                     const int16_t* dispR, ptrdiff_t sR, ptrdiff_t psR,
+                                     const adf_rect* roi_in, void* stream)
+{
+    NEED_HANDLE(h);
+    hipStream_t st = (hipStream_t)stream;
+    // DF.cpp:221-222
+    if (!dispL || W <= 0 || H <= 0) return fail(ADF_EBADARG, "disparity_map_left is empty");
+    if (!view || (gch != 1 && gch != 3)) return fail(ADF_EBADARG, "left_view must be CV_8UC1 or CV_8UC3");
+    if (!out) return fail(ADF_EBADARG, "filtered_disparity_map is NULL");
+    if (n_pairs < 1) return fail(ADF_EBADARG, "n_pairs must be >= 1");
+    if (sL < (ptrdiff_t)W * 2 || sO < (ptrdiff_t)W * 2 || sG < (ptrdiff_t)W * gch)
+        return fail(ADF_ESIZE, "row stride smaller than a row");
+    if (h->use_confidence) { // DF.cpp:262-264
+        if (!dispR) return fail(ADF_EBADARG, "disparity_map_right is required with use_confidence");
+        if (sR < (ptrdiff_t)W * 2) return fail(ADF_ESIZE, "right disparity stride smaller than a row");
+    }
+    if (h->lambda < 0 || h->sigma_color < 0) return fail(ADF_EBADARG, "lambda and sigma_color must be >= 0 (FGS.cpp:143)");
+    // DF.cpp:228-233
+    adf_rect roi;
+    if (roi_in && roi_in->width * roi_in->height != 0) roi = *roi_in;
+    else roi = adf_rect{h->left_offset, h->top_offset, W - h->left_offset - h->right_offset,
+                        H - h->top_offset - h->bottom_offset};
+    if (roi.width <= 0 || roi.height <= 0 || roi.x < 0 || roi.y < 0 || roi.x + roi.width > W ||
+        roi.y + roi.height > H)
+        return fail(ADF_ESIZE, "ROI (%d,%d,%d,%d) does not fit a %dx%d map", roi.x, roi.y, roi.width,
+                    roi.height, W, H);
+    if (h->use_confidence && (h->disc_radius < 0 || h->disc_radius > max_disc_radius()))
+        return fail(ADF_EBADARG, "depth discontinuity radius %d outside [0,%d]", h->disc_radius, max_disc_radius());
+
+    DeviceScope ds(h->device);
+    const Geom g = make_geom(W, H, roi.x, roi.y, roi.width, roi.height);
+    h->roi = roi; h->last_W = W; h->last_H = H; h->last_pairs = n_pairs;
+
+    int rc = h->lut.ensure((float)h->sigma_color, st);
+    if (rc) return rc;
+    const bool conf = h->use_confidence;
+    const size_t per_pair = wls_pair_ws_bytes(g, conf);
+    int chunk = (int)(h->ws_limit / per_pair);
+    if (chunk < 1) chunk = 1;
+    if (chunk > n_pairs) chunk = n_pairs;
+    if ((rc = h->ws.reserve(per_pair * (size_t)chunk, st))) return rc;
+    if (conf && (rc = h->conf.reserve(g.frame * sizeof(float) * (size_t)n_pairs, st))) return rc;
+
+    // carve the workspace
+    float* base = (float*)h->ws.p;
+    auto take = [&](size_t elems) { float* p = base; base += elems * (size_t)chunk; return p; };
+    SolvePlanes p{};
+    p.CH = take(g.plane); p.CV = take(g.plane); p.D = take(g.plane);
+    p.F0 = take(g.plane); p.A0 = take(g.plane); p.B0 = take(g.plane);
+    float *cL = nullptr, *cR = nullptr;
+    if (conf) {
+        p.F1 = take(g.plane); p.A1 = take(g.plane); p.B1 = take(g.plane);
+        cL = take(g.frame); cR = take(g.frame);
+    }
+
+    for (int first = 0; first < n_pairs; first += chunk) {
+        const int n = (n_pairs - first < chunk) ? n_pairs - first : chunk;
+        const int16_t* dL = (const int16_t*)((const char*)dispL + (ptrdiff_t)first * psL);
+        const uint8_t* gv = view + (ptrdiff_t)first * psG;
+        int16_t* o = (int16_t*)((char*)out + (ptrdiff_t)first * psO);
+
+        FillArgs fa{o, sO, psO, g, (int16_t)(16 * (h->min_disp - 1))};    // DF.cpp:254,284
+        HIP_TRY(launch_fill_outside(fa, n, st));
+
+        WeightArgs wa{gv, sG, psG, gch, (const float*)h->lut.dev.p, p.CH, p.CV, ORIENT_T, ORIENT_N, g};
+        HIP_TRY(launch_weights(wa, n, st));                                // FGS.cpp:163-172
+
+        if (conf) {
+            const int16_t* dRp = (const int16_t*)((const char*)dispR + (ptrdiff_t)first * psR);
+            const int rrx = W - (roi.x + roi.width);                       // DF.cpp:202
+            DiscArgs da{dL, sL, psL, roi.x, roi.y, roi.width, roi.height, h->disc_radius, h->roll_off,
+                        cL, W, g.frame};
+            HIP_TRY(launch_discontinuity(da, n, st));                      // DF.cpp:204
+            DiscArgs db{dRp, sR, psR, rrx, roi.y, roi.width, roi.height, h->disc_radius, h->roll_off,
+                        cR, W, g.frame};
+            HIP_TRY(launch_discontinuity(db, n, st));
+            LrcArgs la{dL, sL, psL, dRp, sR, psR, cL, cR, (float*)h->conf.p + (size_t)first * g.frame,
+                       p.A0, p.A1, g, rrx, (int)(1.0f * h->lrc_thresh) /* DF.cpp:318 */, ORIENT_T};
+            HIP_TRY(launch_lrc_prologue(la, n, st));                       // DF.cpp:208-209,288-290
+            FinalOut fo{EPI_WLS_CONF, o, sO, psO, roi.x, roi.y, 1, 0};
+            if ((rc = run_passes_exact(g, p, 2, (float)h->lambda, (float)h->atten, h->num_iter, fo, n, st)))
+                return rc;                                                 // DF.cpp:292-296
+        } else {
+            PlainPrologueArgs pa{dL, sL, psL, ADF_16S, 1, 0, p.A0, g, ORIENT_T};
+            HIP_TRY(launch_plain_prologue(pa, n, st));                     // FGS.cpp:203-205
+            FinalOut fo{EPI_I16, o, sO, psO, roi.x, roi.y, 1, 0};
+            if ((rc = run_passes_exact(g, p, 1, (float)h->lambda, (float)h->atten, h->num_iter, fo, n, st)))
+                return rc;                                                 // DF.cpp:257-258
+        }
+    }
+    return ADF_OK;
+}
+
+extern "C" int adf_wls_filter_host(adf_wls_t* h, int n_pairs,
+                                   const int16_t* dispL, ptrdiff_t sL, ptrdiff_t psL,
+                                   const uint8_t* view, ptrdiff_t sG, ptrdiff_t psG, int gch, int W, int H,
+                                   int16_t* out, ptrdiff_t sO, ptrdiff_t psO,
+                                   const int16_t* dispR, ptrdiff_t sR, ptrdiff_t psR,
+                                   const adf_rect* roi)
+{
+    NEED_HANDLE(h);
+    if (!dispL || !view || !out || W <= 0 || H <= 0 || n_pairs < 1)
+        return fail(ADF_EBADARG, "adf_wls_filter_host: empty input");
+    if (gch != 1 && gch != 3) return fail(ADF_EBADARG, "left_view must be CV_8UC1 or CV_8UC3");
+    if (h->use_confidence && !dispR) return fail(ADF_EBADARG, "disparity_map_right is required with use_confidence");
+    DeviceScope ds(h->device);
+    hipStream_t st = nullptr;
+    // dense device copies: [dispL | dispR | view | out] per batch
+    const size_t dbytes = (size_t)W * H * 2, gbytes = (size_t)W * H * gch;
+    const size_t dpad = (dbytes + 255) / 256 * 256, gpad = (gbytes + 255) / 256 * 256;
+    const size_t need = (size_t)n_pairs * (3 * dpad + gpad);
+    int rc = h->stage.reserve(need, st);
+    if (rc) return rc;
+    char* dLd = (char*)h->stage.p;
+    char* dRd = dLd + (size_t)n_pairs * dpad;
+    char* od = dRd + (size_t)n_pairs * dpad;
+    char* gd = od + (size_t)n_pairs * dpad;
+    for (int k = 0; k < n_pairs; k++) {
+        HIP_TRY(hipMemcpy2DAsync(dLd + k * dpad, (size_t)W * 2, (const char*)dispL + (ptrdiff_t)k * psL, sL,
+                                 (size_t)W * 2, H, hipMemcpyHostToDevice, st));
+        if (dispR)
+            HIP_TRY(hipMemcpy2DAsync(dRd + k * dpad, (size_t)W * 2, (const char*)dispR + (ptrdiff_t)k * psR, sR,
+                                     (size_t)W * 2, H, hipMemcpyHostToDevice, st));
+        HIP_TRY(hipMemcpy2DAsync(gd + k * gpad, (size_t)W * gch, view + (ptrdiff_t)k * psG, sG,
+                                 (size_t)W * gch, H, hipMemcpyHostToDevice, st));
+    }
+    rc = adf_wls_filter_device(h, n_pairs, (const int16_t*)dLd, (ptrdiff_t)W * 2, (ptrdiff_t)dpad,
+                               (const uint8_t*)gd, (ptrdiff_t)W * gch, (ptrdiff_t)gpad, gch, W, H,
+                               (int16_t*)od, (ptrdiff_t)W * 2, (ptrdiff_t)dpad,
+                               dispR ? (const int16_t*)dRd : nullptr, (ptrdiff_t)W * 2, (ptrdiff_t)dpad, roi, st);
+    if (rc) return rc;
+    for (int k = 0; k < n_pairs; k++)
+        HIP_TRY(hipMemcpy2DAsync((char*)out + (ptrdiff_t)k * psO, sO, od + k * dpad, (size_t)W * 2,
+                                 (size_t)W * 2, H, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    return ADF_OK;
+}
+
+static int conf_copy(adf_wls_t* h, int pair, float* dst, ptrdiff_t stride, hipMemcpyKind kind, hipStream_t st)
+{
+    if (!dst) return fail(ADF_EBADARG, "confidence destination is NULL");
+    if (!h->use_confidence || !h->conf.p || h->last_pairs == 0)
+        return fail(ADF_EBADARG, "no confidence map: filter() has not run with use_confidence");
+    if (pair < 0 || pair >= h->last_pairs) return fail(ADF_EBADARG, "pair %d out of range [0,%d)", pair, h->last_pairs);
+    if (stride < (ptrdiff_t)h->last_W * 4) return fail(ADF_ESIZE, "confidence stride smaller than a row");
+    const float* src = (const float*)h->conf.p + (size_t)pair * h->last_W * h->last_H;
+    HIP_TRY(hipMemcpy2DAsync(dst, stride, src, (size_t)h->last_W * 4, (size_t)h->last_W * 4, h->last_H, kind, st));
+    return ADF_OK;
+}
+
+extern "C" int adf_wls_get_confidence_device(adf_wls_t* h, int pair, float* dst, ptrdiff_t stride, void* stream)
+{
+    NEED_HANDLE(h);
+    DeviceScope ds(h->device);
+    return conf_copy(h, pair, dst, stride, hipMemcpyDeviceToDevice, (hipStream_t)stream);
+}
+
+extern "C" int adf_wls_get_confidence_host(adf_wls_t* h, int pair, float* dst, ptrdiff_t stride)
+{
+    NEED_HANDLE(h);
+    DeviceScope ds(h->device);
+    int rc = conf_copy(h, pair, dst, stride, hipMemcpyDeviceToHost, nullptr);
+    if (rc) return rc;
+    HIP_TRY(hipStreamSynchronize(nullptr));
+    return ADF_OK;
+}
+
+// ----------------------------------------------------------------------------------------------
+// FastGlobalSmootherFilter
+// ----------------------------------------------------------------------------------------------
+struct adf_fgs {
+    int device = 0;
+    int w = 0, h = 0;
+    float lambda = 0, sigma = 0, atten = 0.25f; int num_iter = 3; int solver = ADF_SOLVER_EXACT;
+    Geom g{};
+    Lut lut;
+    DevBuf planes; // CH CV D F0 A0 B0
+    DevBuf io;     // src / dst image staging
+};
+
+extern "C" int adf_fgs_create(adf_fgs_t** out, const uint8_t* guide, ptrdiff_t gstride, int gch, int w, int hgt,
+                              double lambda, double sigma_color, double atten, int num_iter, int solver)
+{
+    if (!out) return fail(ADF_EBADARG, "adf_fgs_create: out is NULL");
+    *out = nullptr;
+    // FGS.cpp:143-144
+    if (!guide || w <= 0 || hgt <= 0) return fail(ADF_EBADARG, "guide is empty");
+    if (lambda < 0 || sigma_color < 0 || num_iter < 1) return fail(ADF_EBADARG, "lambda>=0, sigma_color>=0, num_iter>=1 required");
+    if (gch != 1 && gch != 3) return fail(ADF_EBADARG, "guide must be CV_8UC1 or CV_8UC3");
+    if (gstride < (ptrdiff_t)w * gch) return fail(ADF_ESIZE, "guide stride smaller than a row");
+    if (solver != ADF_SOLVER_EXACT) return fail(ADF_EBADARG, "solver %d not available in this build", solver);
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return fail(ADF_ENODEV, "adf_fgs_create: no HIP device visible");
+    adf_fgs* f = new (std::nothrow) adf_fgs();
+    if (!f) return fail(ADF_ENOMEM, "out of host memory");
+    hipGetDevice(&f->device);
+    f->w = w; f->h = hgt;
+    f->lambda = (float)lambda; f->sigma = (float)sigma_color; f->atten = (float)atten; // FGS.cpp:145-147
+    f->num_iter = num_iter; f->solver = solver;
+    f->g = make_geom(w, hgt, 0, 0, w, hgt);
+    hipStream_t st = nullptr;
+    int rc = f->lut.ensure(f->sigma, st);
+    if (!rc) rc = f->planes.reserve(6 * f->g.plane * sizeof(float), st);
+    const size_t gbytes = (size_t)w * hgt * gch;
+    if (!rc) rc = f->io.reserve(gbytes > (size_t)w * hgt * 16 ? gbytes : (size_t)w * hgt * 16, st);
+    if (rc) { adf_fgs_destroy(f); return rc; }
+    hipError_t e = hipMemcpy2D(f->io.p, (size_t)w * gch, guide, gstride, (size_t)w * gch, hgt, hipMemcpyHostToDevice);
+    if (e == hipSuccess) {
+        float* base = (float*)f->planes.p;
+        WeightArgs wa{(const uint8_t*)f->io.p, (ptrdiff_t)w * gch, 0, gch, (const float*)f->lut.dev.p,
+                      base, base + f->g.plane, ORIENT_T, ORIENT_N, f->g};
+        e = launch_weights(wa, 1, st);
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    if (e != hipSuccess) { adf_fgs_destroy(f); return fail(ADF_EHIP, "adf_fgs_create: %s", hipGetErrorString(e)); }
+    *out = f;
+    return ADF_OK;
+}
+
+extern "C" void adf_fgs_destroy(adf_fgs_t* f)
+{
+    if (!f) return;
+    DeviceScope ds(f->device);
+    f->lut.dev.release(); f->planes.release(); f->io.release();
+    delete f;
+}
+
+extern "C" int adf_fgs_filter_host(adf_fgs_t* f, const void* src, ptrdiff_t sstride, void* dst, ptrdiff_t dstride,
+                                   int depth, int channels)
+{
+    NEED_HANDLE(f);
+    // FGS.cpp:184
+    if (!src || !dst) return fail(ADF_EBADARG, "src/dst is empty");
+    if (depth != ADF_8U && depth != ADF_16S && depth != ADF_32F) return fail(ADF_EBADARG, "src depth must be CV_8U, CV_16S or CV_32F");
+    if (channels < 1 || channels > 4) return fail(ADF_EBADARG, "src must have 1..4 channels");
+    const size_t esz = depth == ADF_8U ? 1 : depth == ADF_16S ? 2 : 4;
+    const size_t rowb = (size_t)f->w * channels * esz;
+    if (sstride < (ptrdiff_t)rowb || dstride < (ptrdiff_t)rowb)
+        return fail(ADF_ESIZE, "Size of the filtered image must be equal to the size of the guide image"); // FGS.cpp:187
+    DeviceScope ds(f->device);
+    hipStream_t st = nullptr;
+    char* img = (char*)f->io.p;
+    HIP_TRY(hipMemcpy2DAsync(img, rowb, src, sstride, rowb, f->h, hipMemcpyHostToDevice, st));
+    float* base = (float*)f->planes.p;
+    const Geom& g = f->g;
+    SolvePlanes p{};
+    p.CH = base; p.CV = base + g.plane; p.D = base + 2 * g.plane; p.F0 = base + 3 * g.plane;
+    p.A0 = base + 4 * g.plane; p.B0 = base + 5 * g.plane;
+    const int epi = depth == ADF_8U ? EPI_U8 : depth == ADF_16S ? EPI_I16 : EPI_F32;
+    for (int c = 0; c < channels; c++) { // FGS.cpp:200-221: channels filtered one by one
+        PlainPrologueArgs pa{img, (ptrdiff_t)rowb, 0, depth, channels, c, p.A0, g, ORIENT_T};
+        HIP_TRY(launch_plain_prologue(pa, 1, st));
+        // the epilogue of channel c overwrites only channel c of the staged image, which later
+        // channels never read (they read their own channel), so filtering in place is safe
+        FinalOut fo{epi, img, (ptrdiff_t)rowb, 0, 0, 0, channels, c};
+        int rc = run_passes_exact(g, p, 1, f->lambda, f->atten, f->num_iter, fo, 1, st);
+        if (rc) return rc;
+    }
+    HIP_TRY(hipMemcpy2DAsync(dst, dstride, img, rowb, rowb, f->h, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    return ADF_OK;
+}

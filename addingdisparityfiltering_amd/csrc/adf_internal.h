@@ -1,0 +1,124 @@
+// adf_internal.h -- shared declarations between the HIP kernels and the C-ABI host code.
+// Not installed; the public boundary is include/adf_wls.h.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+
+#define ADF_LUT_LEVELS (3 * 256 * 256) /* FGS.cpp:150 */
+#define ADF_EPS 1e-43f                 /* DF.cpp:47  */
+
+namespace adf {
+
+// Geometry of one filter call.  ROI planes are kept in two orientations:
+//   N ("natural")    [rh][pw] : column index fastest -> lane-per-column (vertical) sweeps coalesce
+//   T ("transposed") [rw][ph] : row index fastest    -> lane-per-row (horizontal) sweeps coalesce
+// pw / ph are rw / rh rounded up to 64 floats so every sweep step is one aligned 256-byte row.
+struct Geom {
+    int W, H;           // full frame
+    int rx, ry, rw, rh; // ROI (DF.cpp:228-233)
+    int pw, ph;         // padded pitches (floats)
+    size_t plane;       // floats per pair per ROI plane = max(rh*pw, rw*ph)
+    size_t frame;       // floats per pair per full-frame plane = W*H
+};
+
+// Destination orientation of a tile-writing kernel.
+enum Orient { ORIENT_N = 0, ORIENT_T = 1 };
+
+// What the last sweep of a solve writes (fused epilogues).
+enum Epilogue {
+    EPI_PLANES = 0,   // float planes in the opposite orientation (feeds the next pass)
+    EPI_WLS_CONF = 1, // int16 = sat(u0 * (1/(u1+EPS)))   DF.cpp:295-296
+    EPI_I16 = 2,      // int16 = sat(u0)                  FGS.cpp:216 (no-confidence path, DF.cpp:257-258)
+    EPI_F32 = 3,      // float natural layout             FGS.cpp:218
+    EPI_U8 = 4        // uint8 = sat(u0)                  FGS.cpp:216
+};
+
+struct DiscArgs {
+    const int16_t* disp; ptrdiff_t stride, pair_stride; // bytes
+    int rx, ry, rw, rh;  // ROI of THIS view
+    int radius; float roll_off;
+    float* dst; int W; size_t frame; // full-frame float plane, W pitch
+};
+
+struct LrcArgs {
+    const int16_t* dL; ptrdiff_t sL, psL; // bytes
+    const int16_t* dR; ptrdiff_t sR, psR;
+    const float* cL; const float* cR; // full-frame discontinuity maps
+    float* conf;                      // full-frame confidence (x255), zero outside ROI
+    float* U0; float* U1;             // ROI planes: conf*disp, conf
+    Geom g; int rrx;                  // right ROI x (DF.cpp:202)
+    int thresh; int orient;           // orientation of U0/U1
+};
+
+// Source plane -> float right-hand side on the ROI: the no-confidence path's float(disp)
+// (DF.cpp:250,257) and FastGlobalSmootherFilter::filter's split + convertTo (FGS.cpp:191-205).
+struct PlainPrologueArgs {
+    const void* src; ptrdiff_t stride, pair_stride; // bytes
+    int depth, cn, c;                               // adf_depth code, channel count, channel index
+    float* U0; Geom g; int orient;
+};
+
+struct WeightArgs {
+    const uint8_t* guide; ptrdiff_t stride, pair_stride; int ch; // bytes
+    const float* lut;
+    float* chor; float* cvert; int chor_orient, cvert_orient;
+    Geom g;
+};
+
+struct FillArgs {
+    int16_t* out; ptrdiff_t stride, pair_stride; // bytes
+    Geom g; int16_t value;
+};
+
+// One solve pass (forward elimination + back substitution along every scanline).
+// Input planes have the scanline index fastest: element (step t, scanline s) at t*pitch_in + s.
+struct PassArgs {
+    const float* C; const float* U0; const float* U1;
+    float* D; float* F0; float* F1; // forward intermediates, same layout as the inputs
+    float* O0; float* O1;           // EPI_PLANES: [nscan][pitch_out], step index fastest
+    void* out; ptrdiff_t out_stride, out_pair_stride; // other epilogues: natural image, bytes
+    int out_x0, out_y0, out_cn, out_c;                // ROI origin, channel count / index of `out`
+    int nscan, len, pitch_in, pitch_out;
+    size_t plane;
+    float lambda;
+};
+
+// Launchers (defined in the .hip files).  All are asynchronous on `st`.
+hipError_t launch_discontinuity(const DiscArgs& a, int n_pairs, hipStream_t st);
+hipError_t launch_lrc_prologue(const LrcArgs& a, int n_pairs, hipStream_t st);
+hipError_t launch_plain_prologue(const PlainPrologueArgs& a, int n_pairs, hipStream_t st);
+hipError_t launch_weights(const WeightArgs& a, int n_pairs, hipStream_t st);
+hipError_t launch_fill_outside(const FillArgs& a, int n_pairs, hipStream_t st);
+hipError_t launch_exact_pass(const PassArgs& a, int n_rhs, int epilogue, int n_pairs, hipStream_t st);
+// largest depth-discontinuity radius the tile kernel supports (LDS bound)
+int max_disc_radius();
+
+// Device-side helpers shared by kernels.
+#if defined(__HIPCC__)
+// saturate_cast<short>(float): cvRound (round-half-even; NaN / out-of-int-range -> INT_MIN) + clamp.
+__device__ __forceinline__ int16_t sat16(float v)
+{
+    if (!(v >= -2147483648.0f && v < 2147483648.0f)) return (int16_t)-32768;
+    float r = rintf(v);
+    r = fminf(fmaxf(r, -32768.0f), 32767.0f);
+    return (int16_t)(int)r;
+}
+__device__ __forceinline__ uint8_t sat8(float v)
+{
+    if (!(v >= -2147483648.0f && v < 2147483648.0f)) return (uint8_t)0;
+    float r = rintf(v);
+    r = fminf(fmaxf(r, 0.0f), 255.0f);
+    return (uint8_t)(int)r;
+}
+// cv::borderInterpolate(p, len, BORDER_REFLECT_101)
+__device__ __forceinline__ int reflect101(int p, int len)
+{
+    if (len == 1) return 0;
+    while (p < 0 || p >= len) p = p < 0 ? -p : 2 * (len - 1) - p;
+    return p;
+}
+#endif
+
+} // namespace adf

@@ -1,0 +1,263 @@
+// conf_kernels.hip -- confidence-map half of DisparityWLSFilter::filter for gfx950.
+//
+//   discontinuity_kernel : DF.cpp:161-194 (box mean / mean of squares on the ROI copy,
+//                          BORDER_REFLECT_101) + DF.cpp:343-373 (variance -> roll-off map)
+//   lrc_prologue_kernel  : DF.cpp:306-341 (discontinuity-aware left-right check), DF.cpp:209
+//                          (x255) and DF.cpp:288-290 (conf*float(disp)), fused; writes the
+//                          two right-hand sides of the solve in the orientation the first
+//                          pass wants
+//   plain_prologue_kernel: source channel -> float right-hand side: the no-confidence path's
+//                          float(disp) (DF.cpp:250,257) and FGS.cpp:191-205 (split + convertTo)
+//   fill_outside_kernel  : out = 16*(min_disp-1) = -16 outside the ROI (DF.cpp:149,254,284)
+//
+// All of this is integer / elementwise float work: HBM-bound, no MFMA.  Arithmetic that must
+// match the CPU restatement bit for bit is written as separate roundings (contraction off).
+#include "adf_internal.h"
+
+#pragma clang fp contract(off)
+
+namespace adf {
+
+namespace {
+
+constexpr int TX = 64; // tile width  (one wavefront wide: 128-byte int16 rows, 256-byte float rows)
+constexpr int TY = 32; // tile height
+constexpr int NT = 256;
+constexpr int MAX_RADIUS = 40;
+
+// ---------------------------------------------------------------------------------------
+// Depth-discontinuity map of one view.  One block = one TX x TY tile of ROI outputs.
+// LDS: int16 input tile with halo, then horizontal window sums (int32 sum, int64 sum of
+// squares; both exact), then vertical window sums by sliding windows of 8 outputs.
+// ---------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(NT) discontinuity_kernel(DiscArgs a)
+{
+    extern __shared__ __align__(16) unsigned char smem[];
+    const int r = a.radius, k = 2 * r + 1;
+    const int IH = TY + 2 * r, IW = TX + 2 * r;
+    long long* h2 = reinterpret_cast<long long*>(smem);                  // [IH][TX]
+    int* h1 = reinterpret_cast<int*>(h2 + (size_t)IH * TX);              // [IH][TX]
+    int16_t* in = reinterpret_cast<int16_t*>(h1 + (size_t)IH * TX);      // [IH][IW]
+
+    const int tid = threadIdx.x;
+    const int x0 = blockIdx.x * TX, y0 = blockIdx.y * TY;
+    const char* base = reinterpret_cast<const char*>(a.disp) + (ptrdiff_t)blockIdx.z * a.pair_stride;
+
+    for (int idx = tid; idx < IH * IW; idx += NT) {
+        int yy = idx / IW, xx = idx - yy * IW;
+        int gy = reflect101(y0 + yy - r, a.rh);
+        int gx = reflect101(x0 + xx - r, a.rw);
+        const int16_t* row = reinterpret_cast<const int16_t*>(base + (ptrdiff_t)(a.ry + gy) * a.stride);
+        in[idx] = row[a.rx + gx];
+    }
+    __syncthreads();
+
+    // horizontal sums: work item = (row, segment of 8 outputs)
+    for (int item = tid; item < IH * (TX / 8); item += NT) {
+        int yy = item / (TX / 8), xs = (item - yy * (TX / 8)) * 8;
+        const int16_t* p = in + yy * IW + xs;
+        int s1 = 0; long long s2 = 0;
+        for (int q = 0; q < k; q++) { int v = p[q]; s1 += v; s2 += (long long)(v * v); }
+        h1[yy * TX + xs] = s1; h2[yy * TX + xs] = s2;
+        for (int i = 1; i < 8; i++) {
+            int va = p[i + k - 1], vb = p[i - 1];
+            s1 += va - vb; s2 += (long long)(va * va) - (long long)(vb * vb);
+            h1[yy * TX + xs + i] = s1; h2[yy * TX + xs + i] = s2;
+        }
+    }
+    __syncthreads();
+
+    // vertical sums: thread = (column, segment of 8 rows)
+    {
+        const int x = tid % TX, ys = (tid / TX) * 8;
+        const double scale = 1.0 / ((double)k * (double)k);
+        int s1 = 0; long long s2 = 0;
+        for (int q = 0; q < k; q++) { s1 += h1[(ys + q) * TX + x]; s2 += h2[(ys + q) * TX + x]; }
+        float* dst = a.dst + (size_t)blockIdx.z * a.frame;
+        for (int i = 0; i < 8; i++) {
+            if (i > 0) {
+                s1 += h1[(ys + i + k - 1) * TX + x] - h1[(ys + i - 1) * TX + x];
+                s2 += h2[(ys + i + k - 1) * TX + x] - h2[(ys + i - 1) * TX + x];
+            }
+            int gy = y0 + ys + i, gx = x0 + x;
+            if (gy < a.rh && gx < a.rw) {
+                float mean = (float)((double)s1 * scale);
+                float sq = (float)((double)s2 * scale);
+                float variance = sq - mean * mean;       // DF.cpp:369
+                float v = 1.0f - a.roll_off * variance;  // DF.cpp:370
+                dst[(size_t)(a.ry + gy) * a.W + a.rx + gx] = v < 0.0f ? 0.0f : v;
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// LRC + x255 + prologue.  Grid covers the full frame so the confidence plane is written
+// exactly once everywhere (zero outside the ROI, DF.cpp:187-190,209).
+// ---------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(NT) lrc_prologue_kernel(LrcArgs a)
+{
+    __shared__ float t0[TX * (TY + 1)];
+    __shared__ float t1[TX * (TY + 1)];
+    const Geom& g = a.g;
+    const int tid = threadIdx.x, tx = tid % TX, ty = tid / TX;
+    const int x0 = blockIdx.x * TX, y0 = blockIdx.y * TY;
+    const size_t pz = blockIdx.z;
+    const char* pL = reinterpret_cast<const char*>(a.dL) + (ptrdiff_t)pz * a.psL;
+    const char* pR = reinterpret_cast<const char*>(a.dR) + (ptrdiff_t)pz * a.psR;
+    const float* cL = a.cL + pz * g.frame;
+    const float* cR = a.cR + pz * g.frame;
+    float* conf = a.conf + pz * g.frame;
+    float* U0 = a.U0 + pz * g.plane;
+    float* U1 = a.U1 + pz * g.plane;
+    const int j = x0 + tx;
+    const int right_end = a.rrx + g.rw;
+
+#pragma unroll
+    for (int kk = 0; kk < TY / 4; kk++) {
+        const int i = y0 + ty + 4 * kk;
+        const bool in_frame = i < g.H && j < g.W;
+        const bool in_roi = in_frame && j >= g.rx && j < g.rx + g.rw && i >= g.ry && i < g.ry + g.rh;
+        float c = 0.0f, u0 = 0.0f;
+        if (in_roi) {
+            const int16_t* rl = reinterpret_cast<const int16_t*>(pL + (ptrdiff_t)i * a.sL);
+            const int d = rl[j];
+            c = cL[(size_t)i * g.W + j];
+            const int ridx = j - (d >> 4);                              // DF.cpp:331
+            if (ridx >= a.rrx && ridx < right_end) {
+                const int16_t* rr = reinterpret_cast<const int16_t*>(pR + (ptrdiff_t)i * a.sR);
+                const int dr = rr[ridx];
+                if (abs(d + dr) < a.thresh) {                           // DF.cpp:334
+                    const float b = cR[(size_t)i * g.W + ridx];
+                    c = b < c ? b : c;                                  // std::min, DF.cpp:335
+                } else
+                    c = 0.0f;                                           // DF.cpp:337
+            }
+            c = 255.0f * c;                                             // DF.cpp:209
+            u0 = c * (float)d;                                          // DF.cpp:289-290
+        }
+        if (in_frame) conf[(size_t)i * g.W + j] = c;
+        if (a.orient == ORIENT_N) {
+            if (in_roi) {
+                size_t o = (size_t)(i - g.ry) * g.pw + (j - g.rx);
+                U0[o] = u0; U1[o] = c;
+            }
+        } else {
+            t0[tx * (TY + 1) + ty + 4 * kk] = u0;
+            t1[tx * (TY + 1) + ty + 4 * kk] = c;
+        }
+    }
+    if (a.orient == ORIENT_T) {
+        __syncthreads();
+#pragma unroll
+        for (int m = 0; m < TX / 8; m++) {
+            const int cidx = tid / TY + 8 * m, ridx = tid % TY;
+            const int jj = x0 + cidx, ii = y0 + ridx;
+            if (jj >= g.rx && jj < g.rx + g.rw && ii >= g.ry && ii < g.ry + g.rh && ii < g.H && jj < g.W) {
+                size_t o = (size_t)(jj - g.rx) * g.ph + (ii - g.ry);
+                U0[o] = t0[cidx * (TY + 1) + ridx];
+                U1[o] = t1[cidx * (TY + 1) + ridx];
+            }
+        }
+    }
+}
+
+__global__ void __launch_bounds__(NT) plain_prologue_kernel(PlainPrologueArgs a)
+{
+    __shared__ float t0[TX * (TY + 1)];
+    const Geom& g = a.g;
+    const int tid = threadIdx.x, tx = tid % TX, ty = tid / TX;
+    const int x0 = blockIdx.x * TX, y0 = blockIdx.y * TY; // ROI coordinates
+    const size_t pz = blockIdx.z;
+    const char* pL = reinterpret_cast<const char*>(a.src) + (ptrdiff_t)pz * a.pair_stride;
+    float* U0 = a.U0 + pz * g.plane;
+    const int j = x0 + tx;
+#pragma unroll
+    for (int kk = 0; kk < TY / 4; kk++) {
+        const int i = y0 + ty + 4 * kk;
+        const bool ok = i < g.rh && j < g.rw;
+        float u0 = 0.0f;
+        if (ok) {
+            const char* row = pL + (ptrdiff_t)(g.ry + i) * a.stride;
+            const size_t e = (size_t)(g.rx + j) * a.cn + a.c;
+            if (a.depth == 3) u0 = (float)reinterpret_cast<const int16_t*>(row)[e];      // CV_16S
+            else if (a.depth == 0) u0 = (float)reinterpret_cast<const uint8_t*>(row)[e]; // CV_8U
+            else u0 = reinterpret_cast<const float*>(row)[e];                            // CV_32F
+        }
+        if (a.orient == ORIENT_N) {
+            if (ok) U0[(size_t)i * g.pw + j] = u0;
+        } else
+            t0[tx * (TY + 1) + ty + 4 * kk] = u0;
+    }
+    if (a.orient == ORIENT_T) {
+        __syncthreads();
+#pragma unroll
+        for (int m = 0; m < TX / 8; m++) {
+            const int cidx = tid / TY + 8 * m, ridx = tid % TY;
+            const int jj = x0 + cidx, ii = y0 + ridx;
+            if (jj < g.rw && ii < g.rh) U0[(size_t)jj * g.ph + ii] = t0[cidx * (TY + 1) + ridx];
+        }
+    }
+}
+
+__global__ void __launch_bounds__(NT) fill_outside_kernel(FillArgs a)
+{
+    const Geom& g = a.g;
+    const int j = blockIdx.x * NT + threadIdx.x, i = blockIdx.y;
+    if (j >= g.W) return;
+    const bool in_roi = j >= g.rx && j < g.rx + g.rw && i >= g.ry && i < g.ry + g.rh;
+    if (in_roi) return;
+    int16_t* row = reinterpret_cast<int16_t*>(reinterpret_cast<char*>(a.out) +
+                                              (ptrdiff_t)blockIdx.z * a.pair_stride + (ptrdiff_t)i * a.stride);
+    row[j] = a.value;
+}
+
+inline size_t disc_lds_bytes(int r)
+{
+    const size_t IH = TY + 2 * r, IW = TX + 2 * r;
+    return IH * TX * 8 + IH * TX * 4 + ((IH * IW * 2 + 15) & ~(size_t)15);
+}
+
+} // namespace
+
+int max_disc_radius() { return MAX_RADIUS; }
+
+hipError_t launch_discontinuity(const DiscArgs& a, int n_pairs, hipStream_t st)
+{
+    if (a.rw <= 0 || a.rh <= 0 || n_pairs <= 0) return hipSuccess;
+    if (a.radius < 0 || a.radius > MAX_RADIUS) return hipErrorInvalidValue;
+    const size_t lds = disc_lds_bytes(a.radius);
+    static size_t configured = 0;
+    if (lds > 48 * 1024 && lds > configured) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(discontinuity_kernel),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        configured = lds;
+    }
+    dim3 grid((a.rw + TX - 1) / TX, (a.rh + TY - 1) / TY, n_pairs);
+    hipLaunchKernelGGL(discontinuity_kernel, grid, dim3(NT), lds, st, a);
+    return hipGetLastError();
+}
+
+hipError_t launch_lrc_prologue(const LrcArgs& a, int n_pairs, hipStream_t st)
+{
+    dim3 grid((a.g.W + TX - 1) / TX, (a.g.H + TY - 1) / TY, n_pairs);
+    hipLaunchKernelGGL(lrc_prologue_kernel, grid, dim3(NT), 0, st, a);
+    return hipGetLastError();
+}
+
+hipError_t launch_plain_prologue(const PlainPrologueArgs& a, int n_pairs, hipStream_t st)
+{
+    dim3 grid((a.g.rw + TX - 1) / TX, (a.g.rh + TY - 1) / TY, n_pairs);
+    hipLaunchKernelGGL(plain_prologue_kernel, grid, dim3(NT), 0, st, a);
+    return hipGetLastError();
+}
+
+hipError_t launch_fill_outside(const FillArgs& a, int n_pairs, hipStream_t st)
+{
+    dim3 grid((a.g.W + NT - 1) / NT, a.g.H, n_pairs);
+    hipLaunchKernelGGL(fill_outside_kernel, grid, dim3(NT), 0, st, a);
+    return hipGetLastError();
+}
+
+} // namespace adf

@@ -1,0 +1,411 @@
+"""Host-side mirror of the reference's operator interface for the disparity-filter path.
+
+Same names, argument meaning and error behaviour as cv::ximgproc in
+modules/ximgproc/include/opencv2/ximgproc/disparity_filter.hpp (DF.hpp) and
+edge_filter.hpp (EF.hpp), over the C-ABI in include/adf_wls.h:
+
+    createDisparityWLSFilter(matcher_left)          DF.hpp:131  / DF.cpp:386-414
+    createRightMatcher(matcher_left)                DF.hpp:139  / DF.cpp:417-449
+    createDisparityWLSFilterGeneric(use_confidence) DF.hpp:149  / DF.cpp:452-455
+    DisparityWLSFilter.filter(...)                  DF.hpp:75   / DF.cpp:219-298
+    DisparityWLSFilter.get*/set*                    DF.hpp:90-122
+    createFastGlobalSmootherFilter(...)             EF.hpp:393
+    fastGlobalSmootherFilter(...)                   EF.hpp:413
+
+Images are numpy arrays (host path: copied to the GPU and back) or torch CUDA
+tensors (device path: zero-copy, asynchronous on torch's current stream).  A
+leading batch dimension filters N independent, equally sized pairs in one call.
+All compute runs in the HIP library; there is no CPU fallback.
+"""
+import ctypes as C
+import math
+
+import numpy as np
+
+from . import _lib
+from ._lib import AdfError, Rect, SOLVER_EXACT, SOLVER_WAVE  # noqa: F401  (re-exported)
+
+try:  # torch is optional plumbing: device memory and streams only
+    import torch
+except Exception:  # pragma: no cover
+    torch = None
+
+
+def _is_torch(a):
+    return torch is not None and isinstance(a, torch.Tensor)
+
+
+def _as_rect(roi):
+    if roi is None:
+        return None
+    if isinstance(roi, Rect):
+        return roi
+    x, y, w, h = roi
+    return Rect(int(x), int(y), int(w), int(h))
+
+
+class _Image:
+    """Pointer + strides of a (N,)H,W(,C) image held by numpy or torch."""
+
+    def __init__(self, arr, dtype_np, what, batched, allow_channels=(1,)):
+        self.keep = arr
+        if _is_torch(arr):
+            if not arr.is_cuda:
+                arr = arr.cpu().numpy()
+            else:
+                want = {np.int16: torch.int16, np.uint8: torch.uint8, np.float32: torch.float32}[dtype_np]
+                if arr.dtype != want:
+                    raise AdfError(_lib.ADF_EBADARG, "%s must have dtype %s" % (what, want))
+                self.device = True
+                shape, strides = tuple(arr.shape), tuple(s * arr.element_size() for s in arr.stride())
+                self.ptr = arr.data_ptr()
+                self.keep = arr
+                self._finish(shape, strides, np.dtype(dtype_np).itemsize, what, batched, allow_channels)
+                return
+        a = np.asarray(arr)
+        if a.dtype != np.dtype(dtype_np):
+            raise AdfError(_lib.ADF_EBADARG, "%s must have dtype %s (got %s)" % (what, np.dtype(dtype_np), a.dtype))
+        self.device = False
+        self.keep = a
+        self.ptr = a.ctypes.data
+        self._finish(a.shape, a.strides, a.itemsize, what, batched, allow_channels)
+
+    def _finish(self, shape, strides, itemsize, what, batched, allow_channels):
+        shape, strides = list(shape), list(strides)
+        nd = len(shape) - (1 if batched else 0)
+        if nd == 2:
+            shape.append(1)
+            strides.append(itemsize)
+        elif nd != 3:
+            raise AdfError(_lib.ADF_EBADARG, "%s has an unsupported shape %s" % (what, tuple(shape)))
+        if not batched:
+            shape.insert(0, 1)
+            strides.insert(0, 0)
+        self.n, self.h, self.w, self.c = shape
+        if self.n < 1 or self.h < 1 or self.w < 1:
+            raise AdfError(_lib.ADF_EBADARG, "%s is empty" % what)
+        if self.c not in allow_channels:
+            raise AdfError(_lib.ADF_EBADARG, "%s must have %s channel(s)" % (what, " or ".join(map(str, allow_channels))))
+        if strides[3] != itemsize or strides[2] != itemsize * self.c:
+            raise AdfError(_lib.ADF_ESIZE, "%s rows must be dense (channel-interleaved, unit pixel stride)" % what)
+        self.pair_stride, self.stride = strides[0], strides[1]
+
+
+def _out_like(img, batched, dtype_np):
+    shape = (img.n, img.h, img.w) if batched else (img.h, img.w)
+    if img.device:
+        tdt = {np.int16: torch.int16, np.float32: torch.float32}[dtype_np]
+        return torch.empty(shape, dtype=tdt, device=img.keep.device)
+    return np.empty(shape, dtype_np)
+
+
+def _stream_of(img):
+    if img.device:
+        return C.c_void_p(torch.cuda.current_stream(img.keep.device).cuda_stream)
+    return None
+
+
+class DisparityFilter:
+    """Main interface for all disparity map filters (DF.hpp:52-76)."""
+
+    def filter(self, disparity_map_left, left_view, filtered_disparity_map=None,
+               disparity_map_right=None, ROI=None, right_view=None):
+        raise NotImplementedError
+
+
+class DisparityWLSFilter(DisparityFilter):
+    """Disparity map filter based on the Weighted Least Squares filter (DF.hpp:82-122)."""
+
+    def __init__(self, use_confidence, left_offset=0, right_offset=0, top_offset=0, bottom_offset=0,
+                 min_disp=0):
+        self._h = C.c_void_p()
+        _lib.check(_lib.lib().adf_wls_create(C.byref(self._h), int(bool(use_confidence)), left_offset,
+                                             right_offset, top_offset, bottom_offset, min_disp))
+        self._use_confidence = bool(use_confidence)
+        self._last = None  # (batched, device, example image) of the last filter call
+
+    def __del__(self):
+        h, self._h = getattr(self, "_h", None), None
+        if h:
+            try:
+                _lib.lib().adf_wls_destroy(h)
+            except Exception:
+                pass
+
+    # ---- parameters (DF.hpp:90-122) ----
+    def _getd(self, fn):
+        v = C.c_double()
+        _lib.check(fn(self._h, C.byref(v)))
+        return v.value
+
+    def _geti(self, fn):
+        v = C.c_int()
+        _lib.check(fn(self._h, C.byref(v)))
+        return v.value
+
+    def getLambda(self):
+        return self._getd(_lib.lib().adf_wls_get_lambda)
+
+    def setLambda(self, _lambda):
+        _lib.check(_lib.lib().adf_wls_set_lambda(self._h, float(_lambda)))
+
+    def getSigmaColor(self):
+        return self._getd(_lib.lib().adf_wls_get_sigma_color)
+
+    def setSigmaColor(self, _sigma_color):
+        _lib.check(_lib.lib().adf_wls_set_sigma_color(self._h, float(_sigma_color)))
+
+    def getLRCthresh(self):
+        return self._geti(_lib.lib().adf_wls_get_lrc_thresh)
+
+    def setLRCthresh(self, _LRC_thresh):
+        _lib.check(_lib.lib().adf_wls_set_lrc_thresh(self._h, int(_LRC_thresh)))
+
+    def getDepthDiscontinuityRadius(self):
+        return self._geti(_lib.lib().adf_wls_get_depth_discontinuity_radius)
+
+    def setDepthDiscontinuityRadius(self, _disc_radius):
+        _lib.check(_lib.lib().adf_wls_set_depth_discontinuity_radius(self._h, int(_disc_radius)))
+
+    # extensions of this implementation (no counterpart in DF.hpp)
+    def setFGSParams(self, lambda_attenuation=0.25, num_iter=3):
+        _lib.check(_lib.lib().adf_wls_set_fgs_params(self._h, float(lambda_attenuation), int(num_iter)))
+
+    def setSolver(self, solver):
+        _lib.check(_lib.lib().adf_wls_set_solver(self._h, int(solver)))
+
+    def getSolver(self):
+        return self._geti(_lib.lib().adf_wls_get_solver)
+
+    def workspaceBytes(self):
+        return int(_lib.lib().adf_wls_workspace_bytes(self._h))
+
+    # ---- DisparityFilter::filter (DF.hpp:75) ----
+    def filter(self, disparity_map_left, left_view, filtered_disparity_map=None,
+               disparity_map_right=None, ROI=None, right_view=None):
+        if disparity_map_left is None:
+            raise AdfError(_lib.ADF_EBADARG, "disparity_map_left is empty")
+        if left_view is None:
+            raise AdfError(_lib.ADF_EBADARG, "left_view is empty")
+        batched = len(disparity_map_left.shape) == 3
+        dl = _Image(disparity_map_left, np.int16, "disparity_map_left", batched)
+        gv = _Image(left_view, np.uint8, "left_view", batched, allow_channels=(1, 3))
+        if (gv.n, gv.h, gv.w) != (dl.n, dl.h, dl.w):
+            # the reference resizes a smaller disparity map to the view (DF.cpp:239-247, 268-277);
+            # that path is not built yet
+            raise AdfError(_lib.ADF_ESIZE, "disparity map and view sizes differ (resize path not built)")
+        dr = None
+        if disparity_map_right is not None and getattr(disparity_map_right, "size", 1) != 0:
+            dr = _Image(disparity_map_right, np.int16, "disparity_map_right", batched)
+            if (dr.n, dr.h, dr.w) != (dl.n, dl.h, dl.w):
+                raise AdfError(_lib.ADF_ESIZE, "left and right disparity maps differ in size")  # DF.cpp:263-264
+        elif self._use_confidence:
+            raise AdfError(_lib.ADF_EBADARG, "disparity_map_right is required with use_confidence")  # DF.cpp:262
+        imgs = [dl, gv] + ([dr] if dr else [])
+        if len({im.device for im in imgs}) != 1:
+            raise AdfError(_lib.ADF_EBADARG, "inputs must all be numpy arrays or all be CUDA tensors")
+        if filtered_disparity_map is None:
+            filtered_disparity_map = _out_like(dl, batched, np.int16)
+        out = _Image(filtered_disparity_map, np.int16, "filtered_disparity_map", batched)
+        if (out.n, out.h, out.w) != (dl.n, dl.h, dl.w) or out.device != dl.device:
+            raise AdfError(_lib.ADF_ESIZE, "filtered_disparity_map has the wrong size or placement")
+        roi = _as_rect(ROI)
+        args = [self._h, dl.n,
+                C.c_void_p(dl.ptr), dl.stride, dl.pair_stride,
+                C.c_void_p(gv.ptr), gv.stride, gv.pair_stride, gv.c, dl.w, dl.h,
+                C.c_void_p(out.ptr), out.stride, out.pair_stride,
+                C.c_void_p(dr.ptr) if dr else None, dr.stride if dr else 0, dr.pair_stride if dr else 0,
+                C.byref(roi) if roi is not None else None]
+        if dl.device:
+            _lib.check(_lib.lib().adf_wls_filter_device(*args, _stream_of(dl)))
+        else:
+            _lib.check(_lib.lib().adf_wls_filter_host(*args))
+        self._last = (batched, dl.device, dl)
+        return filtered_disparity_map
+
+    def getConfidenceMap(self, pair=None):
+        """CV_32F confidence map(s) of the last filter call (DF.hpp:117, DF.cpp:138)."""
+        if self._last is None or not self._use_confidence:
+            return np.zeros((0, 0), np.float32)  # the reference returns an empty Mat
+        batched, device, ex = self._last
+        pairs = range(ex.n) if pair is None else [pair]
+        outs = []
+        for k in pairs:
+            if device:
+                o = torch.empty((ex.h, ex.w), dtype=torch.float32, device=ex.keep.device)
+                _lib.check(_lib.lib().adf_wls_get_confidence_device(self._h, k, C.c_void_p(o.data_ptr()),
+                                                                    ex.w * 4, _stream_of(ex)))
+            else:
+                o = np.empty((ex.h, ex.w), np.float32)
+                _lib.check(_lib.lib().adf_wls_get_confidence_host(self._h, k, C.c_void_p(o.ctypes.data), ex.w * 4))
+            outs.append(o)
+        if pair is not None or not batched:
+            return outs[0]
+        return torch.stack(outs) if device else np.stack(outs)
+
+    def getROI(self):
+        r = Rect()
+        _lib.check(_lib.lib().adf_wls_get_roi(self._h, C.byref(r)))
+        return (r.x, r.y, r.width, r.height)
+
+    def sync(self, stream=None):
+        _lib.check(_lib.lib().adf_wls_sync(self._h, stream))
+
+
+# ---------------------------------------------------------------------------------------------
+# Matchers.  cv::StereoBM / cv::StereoSGBM live in OpenCV's calib3d, which is outside this path;
+# the factories below only need the parameter accessors, so a plain parameter holder stands in.
+# ---------------------------------------------------------------------------------------------
+class StereoMatcher:
+    def __init__(self, minDisparity=0, numDisparities=16, blockSize=3):
+        self.minDisparity, self.numDisparities, self.blockSize = minDisparity, numDisparities, blockSize
+        self.disp12MaxDiff, self.speckleWindowSize, self.uniquenessRatio = -1, 0, 10
+
+    def getMinDisparity(self): return self.minDisparity
+    def setMinDisparity(self, v): self.minDisparity = v
+    def getNumDisparities(self): return self.numDisparities
+    def getBlockSize(self): return self.blockSize
+    def setDisp12MaxDiff(self, v): self.disp12MaxDiff = v
+    def setSpeckleWindowSize(self, v): self.speckleWindowSize = v
+    def setUniquenessRatio(self, v): self.uniquenessRatio = v
+
+
+class StereoBM(StereoMatcher):
+    def __init__(self, numDisparities=0, blockSize=21):
+        super().__init__(0, numDisparities, blockSize)
+        self.textureThreshold = 10
+
+    @staticmethod
+    def create(numDisparities=0, blockSize=21):
+        return StereoBM(numDisparities, blockSize)
+
+    def setTextureThreshold(self, v): self.textureThreshold = v
+
+
+class StereoSGBM(StereoMatcher):
+    def __init__(self, minDisparity=0, numDisparities=16, blockSize=3, P1=0, P2=0, mode=0, preFilterCap=0):
+        super().__init__(minDisparity, numDisparities, blockSize)
+        self.P1, self.P2, self.mode, self.preFilterCap = P1, P2, mode, preFilterCap
+
+    @staticmethod
+    def create(minDisparity=0, numDisparities=16, blockSize=3):
+        return StereoSGBM(minDisparity, numDisparities, blockSize)
+
+    def getP1(self): return self.P1
+    def setP1(self, v): self.P1 = v
+    def getP2(self): return self.P2
+    def setP2(self, v): self.P2 = v
+    def getMode(self): return self.mode
+    def setMode(self, v): self.mode = v
+    def getPreFilterCap(self): return self.preFilterCap
+    def setPreFilterCap(self, v): self.preFilterCap = v
+
+
+def createDisparityWLSFilter(matcher_left):
+    """DF.hpp:131, DF.cpp:386-414: set the filter up from the matcher (and mutate the matcher)."""
+    matcher_left.setDisp12MaxDiff(1000000)
+    matcher_left.setSpeckleWindowSize(0)
+    min_disp = matcher_left.getMinDisparity()
+    num_disp = matcher_left.getNumDisparities()
+    wsize = matcher_left.getBlockSize()
+    wsize2 = wsize // 2
+    if isinstance(matcher_left, StereoBM):
+        matcher_left.setTextureThreshold(0)
+        matcher_left.setUniquenessRatio(0)
+        wls = DisparityWLSFilter(True, max(0, min_disp + num_disp) + wsize2, max(0, -min_disp) + wsize2,
+                                 wsize2, wsize2, min_disp)
+        wls.setDepthDiscontinuityRadius(int(math.ceil(0.33 * wsize)))
+    elif isinstance(matcher_left, StereoSGBM):
+        matcher_left.setUniquenessRatio(0)
+        wls = DisparityWLSFilter(True, max(0, min_disp + num_disp), max(0, -min_disp), 0, 0, min_disp)
+        wls.setDepthDiscontinuityRadius(int(math.ceil(0.5 * wsize)))
+    else:
+        raise AdfError(_lib.ADF_EBADARG, "DisparityWLSFilter natively supports only StereoBM and StereoSGBM")
+    return wls
+
+
+def createRightMatcher(matcher_left):
+    """DF.hpp:139, DF.cpp:417-449."""
+    min_disp = matcher_left.getMinDisparity()
+    num_disp = matcher_left.getNumDisparities()
+    wsize = matcher_left.getBlockSize()
+    if isinstance(matcher_left, StereoBM):
+        right = StereoBM.create(num_disp, wsize)
+        right.setMinDisparity(-(min_disp + num_disp) + 1)
+        right.setTextureThreshold(0)
+        right.setUniquenessRatio(0)
+        right.setDisp12MaxDiff(1000000)
+        right.setSpeckleWindowSize(0)
+        return right
+    if isinstance(matcher_left, StereoSGBM):
+        right = StereoSGBM.create(-(min_disp + num_disp) + 1, num_disp, wsize)
+        right.setUniquenessRatio(0)
+        right.setP1(matcher_left.getP1())
+        right.setP2(matcher_left.getP2())
+        right.setMode(matcher_left.getMode())
+        right.setPreFilterCap(matcher_left.getPreFilterCap())
+        right.setDisp12MaxDiff(1000000)
+        right.setSpeckleWindowSize(0)
+        return right
+    raise AdfError(_lib.ADF_EBADARG, "createRightMatcher supports only StereoBM and StereoSGBM")
+
+
+def createDisparityWLSFilterGeneric(use_confidence):
+    """DF.hpp:149, DF.cpp:452-455."""
+    return DisparityWLSFilter(use_confidence)
+
+
+# ---------------------------------------------------------------------------------------------
+# Fast Global Smoother (EF.hpp:361-413)
+# ---------------------------------------------------------------------------------------------
+class FastGlobalSmootherFilter:
+    def __init__(self, guide, lambda_, sigma_color, lambda_attenuation=0.25, num_iter=3, solver=SOLVER_EXACT):
+        if guide is None or getattr(guide, "size", 0) == 0:
+            raise AdfError(_lib.ADF_EBADARG, "guide is empty")  # FGS.cpp:143
+        g = np.ascontiguousarray(guide)
+        if g.dtype != np.uint8 or g.ndim not in (2, 3) or (g.ndim == 3 and g.shape[2] not in (1, 3)):
+            raise AdfError(_lib.ADF_EBADARG, "guide must be CV_8UC1 or CV_8UC3")  # FGS.cpp:144
+        ch = 1 if g.ndim == 2 else g.shape[2]
+        self._shape = g.shape[:2]
+        self._h = C.c_void_p()
+        _lib.check(_lib.lib().adf_fgs_create(C.byref(self._h), C.c_void_p(g.ctypes.data), g.shape[1] * ch, ch,
+                                             g.shape[1], g.shape[0], float(lambda_), float(sigma_color),
+                                             float(lambda_attenuation), int(num_iter), int(solver)))
+
+    def __del__(self):
+        h, self._h = getattr(self, "_h", None), None
+        if h:
+            try:
+                _lib.lib().adf_fgs_destroy(h)
+            except Exception:
+                pass
+
+    def filter(self, src, dst=None):
+        """EF.hpp:370, FGS.cpp:182-233."""
+        s = np.ascontiguousarray(src)
+        depth = {np.dtype(np.uint8): _lib.DEPTH_8U, np.dtype(np.int16): _lib.DEPTH_16S,
+                 np.dtype(np.float32): _lib.DEPTH_32F}.get(s.dtype)
+        if depth is None or s.ndim not in (2, 3):
+            raise AdfError(_lib.ADF_EBADARG, "src depth must be CV_8U, CV_16S or CV_32F")  # FGS.cpp:184
+        cn = 1 if s.ndim == 2 else s.shape[2]
+        if cn > 4:
+            raise AdfError(_lib.ADF_EBADARG, "src must have at most 4 channels")
+        if s.shape[:2] != self._shape:
+            raise AdfError(_lib.ADF_ESIZE,
+                           "Size of the filtered image must be equal to the size of the guide image")  # FGS.cpp:187
+        if dst is None:
+            dst = np.empty_like(s)
+        rowb = s.shape[1] * cn * s.itemsize
+        _lib.check(_lib.lib().adf_fgs_filter_host(self._h, C.c_void_p(s.ctypes.data), rowb,
+                                                  C.c_void_p(dst.ctypes.data), rowb, depth, cn))
+        return dst
+
+
+def createFastGlobalSmootherFilter(guide, lambda_, sigma_color, lambda_attenuation=0.25, num_iter=3):
+    """EF.hpp:393."""
+    return FastGlobalSmootherFilter(guide, lambda_, sigma_color, lambda_attenuation, num_iter)
+
+
+def fastGlobalSmootherFilter(guide, src, lambda_, sigma_color, lambda_attenuation=0.25, num_iter=3, dst=None):
+    """EF.hpp:413, FGS.cpp:687-691."""
+    return createFastGlobalSmootherFilter(guide, lambda_, sigma_color, lambda_attenuation, num_iter).filter(src, dst)

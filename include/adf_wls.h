@@ -1,0 +1,154 @@
+/*
+ * adf_wls.h -- C-ABI of the MI355X-native DisparityWLSFilter / FastGlobalSmoother path.
+ *
+ * This is the drop-in boundary: plain pointers, sizes and strides, no C++ and no
+ * torch types.  Every entry point names the reference interface it replaces
+ * (paths relative to the reference tree):
+ *   DF.hpp  = modules/ximgproc/include/opencv2/ximgproc/disparity_filter.hpp
+ *   DF.cpp  = modules/ximgproc/src/disparity_filters.cpp
+ *   EF.hpp  = modules/ximgproc/include/opencv2/ximgproc/edge_filter.hpp
+ *   FGS.cpp = modules/ximgproc/src/fgs_filter.cpp
+ *
+ * Conventions
+ *   - all strides are in BYTES; images are row-major, channels interleaved;
+ *   - "_device" entry points take HIP device pointers and run asynchronously on
+ *     `stream` (a hipStream_t passed as void*, NULL = default stream);
+ *     "_host" entry points take host pointers, copy, run and synchronise;
+ *   - a handle owns a device workspace that is sized on first use and reused; a
+ *     handle serves one caller at a time (the reference objects are not
+ *     re-entrant either: DF.cpp:224-233, FGS.cpp:202-223);
+ *   - every function returns ADF_OK or an error code; adf_last_error() gives the
+ *     message of the calling thread's last failure (the reference throws
+ *     cv::Exception from CV_Assert / CV_Error: DF.cpp:221-222,262-264,
+ *     FGS.cpp:143-144,184-189 -- a C++ adaptor turns codes back into exceptions).
+ */
+#ifndef ADF_WLS_H
+#define ADF_WLS_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ADF_VERSION 100
+
+enum adf_status {
+    ADF_OK = 0,
+    ADF_EBADARG = 1, /* CV_Assert on types / emptiness            DF.cpp:221-222,262 */
+    ADF_ESIZE = 2,   /* size mismatch (Error::StsBadSize)         DF.cpp:263-264, FGS.cpp:185-189 */
+    ADF_EHIP = 3,    /* a HIP runtime call failed                                       */
+    ADF_ENOMEM = 4,  /* workspace allocation failed                                     */
+    ADF_ENODEV = 5   /* no usable gfx950 device                                         */
+};
+
+/* Thomas-solve strategy (no counterpart in the reference, which picks its own
+ * floating-point order per stripe: FGS.cpp:466-476).
+ *   ADF_SOLVER_EXACT : one lane per scanline, canonical scalar order of
+ *                      process_row (FGS.cpp:439-464); bit-identical to the CPU
+ *                      restatement in oracle/.
+ *   ADF_SOLVER_WAVE  : one wavefront per scanline, partitioned solve held in
+ *                      registers/LDS; re-associated arithmetic, within the
+ *                      reference's own reproducibility tolerance (<=1 LSB of the
+ *                      CV_16S output, test_disparity_wls_filter.cpp:104-105). */
+enum adf_solver { ADF_SOLVER_EXACT = 0, ADF_SOLVER_WAVE = 1 };
+
+/* cv::Mat depth codes for adf_fgs_filter_* (FGS.cpp:184). */
+enum adf_depth { ADF_8U = 0, ADF_16S = 3, ADF_32F = 5 };
+
+typedef struct adf_wls adf_wls_t; /* cv::Ptr<DisparityWLSFilter>        */
+typedef struct adf_fgs adf_fgs_t; /* cv::Ptr<FastGlobalSmootherFilter>  */
+
+typedef struct adf_rect { int x, y, width, height; } adf_rect; /* cv::Rect */
+
+int adf_version(void);
+const char* adf_last_error(void);
+/* Number of visible HIP devices (0 when none); never fails. */
+int adf_device_count(void);
+
+/* ---------------- DisparityWLSFilter ---------------- */
+
+/* DisparityWLSFilterImpl::create + init (DF.cpp:142-159, 212-217), reached through
+ * createDisparityWLSFilterGeneric(use_confidence) (DF.hpp:149, DF.cpp:452-455; all
+ * offsets 0) or createDisparityWLSFilter(matcher) (DF.hpp:131, DF.cpp:386-414; the
+ * caller derives the offsets from the matcher).
+ * Defaults as the reference: lambda 8000, sigma_color 1.0, LRC_thresh 24,
+ * depth_discontinuity_radius 5; min_disp is accepted and ignored (DF.cpp:146,149). */
+int adf_wls_create(adf_wls_t** out, int use_confidence, int left_offset, int right_offset,
+                   int top_offset, int bottom_offset, int min_disp);
+void adf_wls_destroy(adf_wls_t* h);
+
+/* DisparityWLSFilter get/set (DF.hpp:90-122, DF.cpp:126-136). */
+int adf_wls_set_lambda(adf_wls_t* h, double lambda);
+int adf_wls_get_lambda(const adf_wls_t* h, double* lambda);
+int adf_wls_set_sigma_color(adf_wls_t* h, double sigma_color);
+int adf_wls_get_sigma_color(const adf_wls_t* h, double* sigma_color);
+int adf_wls_set_lrc_thresh(adf_wls_t* h, int lrc_thresh);
+int adf_wls_get_lrc_thresh(const adf_wls_t* h, int* lrc_thresh);
+int adf_wls_set_depth_discontinuity_radius(adf_wls_t* h, int radius);
+int adf_wls_get_depth_discontinuity_radius(const adf_wls_t* h, int* radius);
+
+/* The inner smoother's parameters, fixed to (0.25, 3) by the reference call site
+ * createFastGlobalSmootherFilter(src, lambda, sigma_color) (DF.cpp:292, EF.hpp:393);
+ * exposed because BASELINE config 5 names num_iter explicitly. */
+int adf_wls_set_fgs_params(adf_wls_t* h, double lambda_attenuation, int num_iter);
+int adf_wls_set_solver(adf_wls_t* h, int solver);
+int adf_wls_get_solver(const adf_wls_t* h, int* solver);
+
+/* DisparityFilter::filter (DF.hpp:75, DF.cpp:219-298) on a batch of n_pairs
+ * independent, equally sized stereo pairs laid out `*_pair_stride` bytes apart
+ * (n_pairs = 1 is the reference call).  disparity maps: CV_16SC1 (disparity*16),
+ * W x H; left_view: CV_8UC1 / CV_8UC3 (view_channels), same size; out: CV_16SC1,
+ * W x H, filled with -16 outside the ROI (DF.cpp:254,284).  disp_right may be
+ * NULL only for a filter created with use_confidence = 0.  roi: NULL or zero
+ * area = derive from the offsets given at creation (DF.cpp:228-233). */
+int adf_wls_filter_device(adf_wls_t* h, int n_pairs,
+                          const int16_t* disp_left, ptrdiff_t disp_left_stride, ptrdiff_t disp_left_pair_stride,
+                          const uint8_t* left_view, ptrdiff_t view_stride, ptrdiff_t view_pair_stride,
+                          int view_channels, int W, int H,
+                          int16_t* out, ptrdiff_t out_stride, ptrdiff_t out_pair_stride,
+                          const int16_t* disp_right, ptrdiff_t disp_right_stride, ptrdiff_t disp_right_pair_stride,
+                          const adf_rect* roi, void* stream);
+
+int adf_wls_filter_host(adf_wls_t* h, int n_pairs,
+                        const int16_t* disp_left, ptrdiff_t disp_left_stride, ptrdiff_t disp_left_pair_stride,
+                        const uint8_t* left_view, ptrdiff_t view_stride, ptrdiff_t view_pair_stride,
+                        int view_channels, int W, int H,
+                        int16_t* out, ptrdiff_t out_stride, ptrdiff_t out_pair_stride,
+                        const int16_t* disp_right, ptrdiff_t disp_right_stride, ptrdiff_t disp_right_pair_stride,
+                        const adf_rect* roi);
+
+/* getConfidenceMap() (DF.hpp:117, DF.cpp:138): CV_32FC1, W x H, values in [0,255],
+ * zero outside the ROI, of pair `pair` of the last filter call.  Valid until the
+ * next filter call on the handle. */
+int adf_wls_get_confidence_device(adf_wls_t* h, int pair, float* dst, ptrdiff_t dst_stride, void* stream);
+int adf_wls_get_confidence_host(adf_wls_t* h, int pair, float* dst, ptrdiff_t dst_stride);
+/* getROI() (DF.hpp:120, DF.cpp:139): ROI used by the last filter call. */
+int adf_wls_get_roi(const adf_wls_t* h, adf_rect* roi);
+/* Block until everything the handle queued on `stream` has finished. */
+int adf_wls_sync(adf_wls_t* h, void* stream);
+/* Bytes of device workspace currently owned by the handle. */
+size_t adf_wls_workspace_bytes(const adf_wls_t* h);
+
+/* ---------------- FastGlobalSmootherFilter ---------------- */
+
+/* createFastGlobalSmootherFilter(guide, lambda, sigma_color, lambda_attenuation,
+ * num_iter) (EF.hpp:393, FGS.cpp:141-180, 681-684).  guide: CV_8UC1 / CV_8UC3,
+ * w x h, HOST pointer (copied).  The weights are built once and reused by every
+ * filter call, as in the reference. */
+int adf_fgs_create(adf_fgs_t** out, const uint8_t* guide, ptrdiff_t guide_stride, int guide_channels,
+                   int w, int h, double lambda, double sigma_color, double lambda_attenuation,
+                   int num_iter, int solver);
+void adf_fgs_destroy(adf_fgs_t* h);
+
+/* FastGlobalSmootherFilter::filter(src, dst) (EF.hpp:370, FGS.cpp:182-233).
+ * src/dst: HOST pointers, same size as the guide, depth ADF_8U / ADF_16S / ADF_32F,
+ * 1..4 interleaved channels; dst may alias src. */
+int adf_fgs_filter_host(adf_fgs_t* h, const void* src, ptrdiff_t src_stride, void* dst,
+                        ptrdiff_t dst_stride, int depth, int channels);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,192 @@
+"""ctypes front-end of the CPU oracle (oracle/adf_oracle.c).
+
+TEST INFRASTRUCTURE ONLY: importable from tests/, __graft_entry__.smoke() and
+bench.py's cpu_baseline leg.  The product package never imports this module.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "libadf_oracle.so")
+
+ORDER_SCALAR = 0
+ORDER_REF_SIMD = 1
+DEPTH_8U, DEPTH_16S, DEPTH_32F = 0, 3, 5
+LUT_LEVELS = 3 * 256 * 256
+
+
+class Params(C.Structure):
+    _fields_ = [
+        ("lambda_", C.c_double),
+        ("sigma_color", C.c_double),
+        ("use_confidence", C.c_int),
+        ("lrc_thresh", C.c_int),
+        ("disc_radius", C.c_int),
+        ("num_iter", C.c_int),
+        ("lambda_attenuation", C.c_double),
+        ("order", C.c_int),
+        ("threads", C.c_int),
+    ]
+
+
+def build(force=False):
+    """Compile the oracle with gcc (oracle/Makefile)."""
+    src_m = max(os.path.getmtime(os.path.join(_HERE, f)) for f in ("adf_oracle.c", "adf_oracle.h"))
+    if force or not os.path.exists(_LIB_PATH) or os.path.getmtime(_LIB_PATH) < src_m:
+        subprocess.run(["make", "-C", _HERE, "-B", "libadf_oracle.so"], check=True,
+                       stdout=subprocess.DEVNULL)
+    return _LIB_PATH
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_LIB_PATH):
+            build()
+        L = C.CDLL(_LIB_PATH)
+        vp, i, f, d, pd = C.c_void_p, C.c_int, C.c_float, C.c_double, C.c_ssize_t
+        L.adf_oracle_default_params.argtypes = [C.POINTER(Params)]
+        L.adf_oracle_lut.argtypes = [f, vp]
+        L.adf_oracle_weights.argtypes = [vp, pd, i, i, i, vp, vp, vp, i]
+        L.adf_oracle_hpass.argtypes = [vp, vp, vp, i, i, f, i, i]
+        L.adf_oracle_vpass.argtypes = [vp, vp, vp, i, i, f, i, i]
+        L.adf_oracle_fgs_planes.argtypes = [vp, pd, i, i, i, vp, i, d, d, d, i, i, i]
+        L.adf_oracle_fgs_planes.restype = i
+        L.adf_oracle_fgs_filter.argtypes = [vp, pd, i, i, i, vp, vp, i, i, d, d, d, i, i, i]
+        L.adf_oracle_fgs_filter.restype = i
+        L.adf_oracle_discontinuity.argtypes = [vp, pd, i, i, i, i, i, i, i, f, vp, i]
+        L.adf_oracle_confidence.argtypes = [vp, pd, vp, pd, i, i, i, i, i, i, i, i, f, vp, i]
+        L.adf_oracle_wls_filter.argtypes = [C.POINTER(Params), vp, pd, vp, pd, i, i, i, vp, pd,
+                                            i, i, i, i, vp, pd, vp]
+        L.adf_oracle_wls_filter.restype = i
+        L.adf_oracle_sat16.argtypes = [f]
+        L.adf_oracle_sat16.restype = C.c_int16
+        _lib = L
+    return _lib
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def default_params(**kw):
+    p = Params()
+    lib().adf_oracle_default_params(C.byref(p))
+    for k, v in kw.items():
+        setattr(p, "lambda_" if k == "lambda" else k, v)
+    return p
+
+
+def lut(sigma):
+    out = np.empty(LUT_LEVELS, np.float32)
+    lib().adf_oracle_lut(float(sigma), _p(out))
+    return out
+
+
+def _guide(guide):
+    g = np.ascontiguousarray(guide, np.uint8)
+    ch = 1 if g.ndim == 2 else g.shape[2]
+    h, w = g.shape[:2]
+    return g, ch, w, h, w * ch
+
+
+def weights(guide, sigma, threads=1):
+    g, ch, w, h, stride = _guide(guide)
+    chor = np.empty((h, w), np.float32)
+    cvert = np.empty((h, w), np.float32)
+    table = lut(sigma)
+    lib().adf_oracle_weights(_p(g), stride, ch, w, h, _p(table), _p(chor), _p(cvert), threads)
+    return chor, cvert
+
+
+def hpass(cur, chor, lam, order=ORDER_SCALAR, threads=1):
+    cur = np.array(cur, np.float32, order="C")
+    h, w = cur.shape
+    inter = np.empty_like(cur)
+    lib().adf_oracle_hpass(_p(cur), _p(np.ascontiguousarray(chor, np.float32)), _p(inter), w, h,
+                           float(lam), order, threads)
+    return cur, inter
+
+
+def vpass(cur, cvert, lam, order=ORDER_SCALAR, threads=1):
+    cur = np.array(cur, np.float32, order="C")
+    h, w = cur.shape
+    inter = np.empty_like(cur)
+    lib().adf_oracle_vpass(_p(cur), _p(np.ascontiguousarray(cvert, np.float32)), _p(inter), w, h,
+                           float(lam), order, threads)
+    return cur, inter
+
+
+def fgs_planes(guide, planes, lam, sigma, atten=0.25, num_iter=3, order=ORDER_SCALAR, threads=1):
+    """planes: (n, h, w) float32 filtered with one shared set of weights."""
+    g, ch, w, h, stride = _guide(guide)
+    pl = np.array(planes, np.float32, order="C")
+    assert pl.shape[1:] == (h, w)
+    rc = lib().adf_oracle_fgs_planes(_p(g), stride, ch, w, h, _p(pl), pl.shape[0], lam, sigma,
+                                     atten, num_iter, order, threads)
+    if rc:
+        raise ValueError("adf_oracle_fgs_planes rc=%d" % rc)
+    return pl
+
+
+def fgs_filter(guide, src, lam, sigma, atten=0.25, num_iter=3, order=ORDER_SCALAR, threads=1):
+    """fastGlobalSmootherFilter(guide, src, dst, ...) restated (EF.hpp:413)."""
+    g, ch, w, h, stride = _guide(guide)
+    s = np.ascontiguousarray(src)
+    depth = {np.dtype(np.uint8): DEPTH_8U, np.dtype(np.int16): DEPTH_16S,
+             np.dtype(np.float32): DEPTH_32F}[s.dtype]
+    channels = 1 if s.ndim == 2 else s.shape[2]
+    dst = np.empty_like(s)
+    rc = lib().adf_oracle_fgs_filter(_p(g), stride, ch, w, h, _p(s), _p(dst), depth, channels,
+                                     lam, sigma, atten, num_iter, order, threads)
+    if rc:
+        raise ValueError("adf_oracle_fgs_filter rc=%d" % rc)
+    return dst
+
+
+def discontinuity(disp, roi, radius, roll_off=0.001, threads=1):
+    d = np.ascontiguousarray(disp, np.int16)
+    H, W = d.shape
+    out = np.empty((H, W), np.float32)
+    lib().adf_oracle_discontinuity(_p(d), W * 2, W, H, roi[0], roi[1], roi[2], roi[3], radius,
+                                   float(np.float32(roll_off)), _p(out), threads)
+    return out
+
+
+def confidence(dispL, dispR, roi, radius=5, lrc_thresh=24, resize_factor=1.0, threads=1):
+    dl = np.ascontiguousarray(dispL, np.int16)
+    dr = np.ascontiguousarray(dispR, np.int16)
+    H, W = dl.shape
+    out = np.empty((H, W), np.float32)
+    lib().adf_oracle_confidence(_p(dl), W * 2, _p(dr), W * 2, W, H, roi[0], roi[1], roi[2],
+                                roi[3], radius, lrc_thresh, resize_factor, _p(out), threads)
+    return out
+
+
+def wls_filter(dispL, guide, dispR, roi, params=None, want_conf=True):
+    """DisparityWLSFilter::filter restated; returns (filtered int16, confidence float32|None)."""
+    p = params if params is not None else default_params()
+    dl = np.ascontiguousarray(dispL, np.int16)
+    H, W = dl.shape
+    g, ch, gw, gh, gstride = _guide(guide)
+    assert (gw, gh) == (W, H)
+    dr = None if dispR is None else np.ascontiguousarray(dispR, np.int16)
+    out = np.empty((H, W), np.int16)
+    conf = np.empty((H, W), np.float32) if want_conf else None
+    rc = lib().adf_oracle_wls_filter(C.byref(p), _p(dl), W * 2, _p(g), gstride, ch, W, H,
+                                     None if dr is None else _p(dr), W * 2,
+                                     roi[0], roi[1], roi[2], roi[3], _p(out), W * 2,
+                                     None if conf is None else _p(conf))
+    if rc:
+        raise ValueError("adf_oracle_wls_filter rc=%d" % rc)
+    return out, conf
+
+
+def sat16(v):
+    return int(lib().adf_oracle_sat16(float(v)))

@@ -1,0 +1,129 @@
+/*
+ * adf_oracle.h -- CPU restatement of the DisparityWLSFilter hot path.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Nothing under oracle/ is part of the product:
+ * only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may
+ * load this library, and only as the checker / the timed CPU baseline.
+ *
+ * Every function cites the reference lines it restates.  Shorthand:
+ *   DF.cpp  = modules/ximgproc/src/disparity_filters.cpp
+ *   FGS.cpp = modules/ximgproc/src/fgs_filter.cpp
+ *   EF.hpp  = modules/ximgproc/include/opencv2/ximgproc/edge_filter.hpp
+ *
+ * Pinning status (see DESIGN.md "Oracle"):
+ *   - the reference cannot be built here (needs OpenCV core/imgproc headers
+ *     and libraries that the image lacks), and its golden images live in
+ *     opencv_extra which is not in the tree;
+ *   - the oracle is pinned by the known-answer / invariant tests the
+ *     reference itself holds for this path (T_FGS:59-87 constant-surface,
+ *     T_DF:99-153 / T_FGS:109-151 order-reproducibility at <=1 LSB) and by
+ *     an independent float64 banded solve (oracle/banded_f64.py);
+ *   - the OpenCV-imgproc boundary (boxFilter / sqrBoxFilter normalisation,
+ *     resize) has no in-tree known answer: "parity unpinned" there.
+ */
+#ifndef ADF_ORACLE_H
+#define ADF_ORACLE_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Floating-point evaluation order of the Thomas denominator.
+ * SCALAR   : ((1-cp)-cc) - D*cp          FGS.cpp:455 (process_row), :369, :553
+ * REF_SIMD : H pass (1-(cc+cp)) - D*cp   FGS.cpp:305-310 inside 4-row blocks,
+ *            V pass 1-((cp+cc)+D*cp)     FGS.cpp:526-534 inside 4-column groups,
+ *            scalar order for the leftovers, exactly as the reference's
+ *            CV_SIMD128 build arranges them per stripe. */
+enum { ADF_ORDER_SCALAR = 0, ADF_ORDER_REF_SIMD = 1 };
+
+/* Source depths accepted by FastGlobalSmootherFilter::filter (FGS.cpp:184). */
+enum { ADF_DEPTH_8U = 0, ADF_DEPTH_16S = 3, ADF_DEPTH_32F = 5 };
+
+typedef struct adf_oracle_params {
+    double lambda;             /* DF.cpp:150, default 8000 (DF.cpp:215)      */
+    double sigma_color;        /* DF.cpp:151, default 1.0  (DF.cpp:215)      */
+    int    use_confidence;     /* DF.cpp:152                                 */
+    int    lrc_thresh;         /* DF.cpp:154, default 24                     */
+    int    disc_radius;        /* DF.cpp:155, default 5                      */
+    int    num_iter;           /* EF.hpp:393 default 3 (DF.cpp:292 call)     */
+    double lambda_attenuation; /* EF.hpp:393 default 0.25                    */
+    int    order;              /* ADF_ORDER_*                                */
+    int    threads;            /* num_stripes = getNumThreads() DF.cpp:158   */
+} adf_oracle_params;
+
+void adf_oracle_default_params(adf_oracle_params* p);
+
+/* FGS.cpp:663-675  LUT[i] = -expf(-sqrtf(i)/sigma), i in [0, 3*256*256). */
+void adf_oracle_lut(float sigma, float* lut);
+
+/* FGS.cpp:586-661  horizontal / vertical edge weights of a guide view.
+ * guide: h rows of w pixels, `ch` interleaved uint8 channels, row stride in
+ * bytes.  chor / cvert: dense h*w float. */
+void adf_oracle_weights(const uint8_t* guide, ptrdiff_t stride, int ch,
+                        int w, int h, const float* lut,
+                        float* chor, float* cvert, int threads);
+
+/* FGS.cpp:235-584  one horizontal / vertical pass, in place on `cur`
+ * (dense h*w), scratch interD (dense h*w). */
+void adf_oracle_hpass(float* cur, const float* chor, float* interD,
+                      int w, int h, float lambda, int order, int threads);
+void adf_oracle_vpass(float* cur, const float* cvert, float* interD,
+                      int w, int h, float lambda, int order, int threads);
+
+/* FGS.cpp:141-233  createFastGlobalSmootherFilter + filter on float planes.
+ * planes: nplanes dense h*w float images filtered in place with one shared
+ * set of weights (what DF.cpp:292-294 does with its two sources). */
+int adf_oracle_fgs_planes(const uint8_t* guide, ptrdiff_t stride, int ch,
+                          int w, int h, float* planes, int nplanes,
+                          double lambda, double sigma_color,
+                          double lambda_attenuation, int num_iter,
+                          int order, int threads);
+
+/* FGS.cpp:182-233, :687-691  generic fastGlobalSmootherFilter: src/dst of
+ * depth 8U / 16S / 32F with 1..4 interleaved channels, dense rows. */
+int adf_oracle_fgs_filter(const uint8_t* guide, ptrdiff_t gstride, int gch,
+                          int w, int h, const void* src, void* dst,
+                          int depth, int channels,
+                          double lambda, double sigma_color,
+                          double lambda_attenuation, int num_iter,
+                          int order, int threads);
+
+/* DF.cpp:161-194 + :343-373  depth-discontinuity map of one view.
+ * disp: H rows x W int16 (stride bytes); ROI (rx,ry,rw,rh); dst dense H*W
+ * float, zero outside the ROI.  roll_off = 0.001f/resize_factor^2. */
+void adf_oracle_discontinuity(const int16_t* disp, ptrdiff_t stride,
+                              int W, int H, int rx, int ry, int rw, int rh,
+                              int radius, float roll_off, float* dst,
+                              int threads);
+
+/* DF.cpp:197-210 + :306-341  confidence map (already multiplied by 255).
+ * conf: dense H*W float. */
+void adf_oracle_confidence(const int16_t* dispL, ptrdiff_t strideL,
+                           const int16_t* dispR, ptrdiff_t strideR,
+                           int W, int H, int rx, int ry, int rw, int rh,
+                           int radius, int lrc_thresh, float resize_factor,
+                           float* conf, int threads);
+
+/* DF.cpp:219-298  DisparityWLSFilterImpl::filter, same-size disparity/view.
+ * ROI with rw*rh == 0 is rejected (the caller resolves offsets, DF.cpp:228-233).
+ * out: H rows x W int16 (stride bytes).  conf_out: nullable dense H*W float
+ * (getConfidenceMap, DF.cpp:138). */
+int adf_oracle_wls_filter(const adf_oracle_params* p,
+                          const int16_t* dispL, ptrdiff_t strideL,
+                          const uint8_t* guide, ptrdiff_t strideG, int gch,
+                          int W, int H,
+                          const int16_t* dispR, ptrdiff_t strideR,
+                          int rx, int ry, int rw, int rh,
+                          int16_t* out, ptrdiff_t strideO, float* conf_out);
+
+/* saturate_cast<short>(float) = cvRound + clamp (DF.cpp:296, FGS.cpp:216);
+ * exported so tests can probe the rounding convention directly. */
+int16_t adf_oracle_sat16(float v);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
