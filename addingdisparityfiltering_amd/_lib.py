@@ -22,6 +22,11 @@ class AdfError(RuntimeError):
         self.code = code
 
 
+class KernelTime(C.Structure):
+    _fields_ = [("name", C.c_char * 48), ("launches", C.c_int), ("total_ms", C.c_double),
+                ("alg_bytes", C.c_double), ("moved_bytes", C.c_double)]
+
+
 class Rect(C.Structure):
     _fields_ = [("x", C.c_int), ("y", C.c_int), ("width", C.c_int), ("height", C.c_int)]
 
@@ -54,6 +59,8 @@ SYMBOLS = [
     ("adf_wls_get_roi", _i, [_vp, C.POINTER(Rect)]),
     ("adf_wls_sync", _i, [_vp, _vp]),
     ("adf_wls_workspace_bytes", _sz, [_vp]),
+    ("adf_wls_profile_enable", _i, [_vp, _i]),
+    ("adf_wls_profile_read", _i, [_vp, _vp, _i, C.POINTER(_i)]),
     ("adf_fgs_create", _i, [C.POINTER(_vp), _vp, _pd, _i, _i, _i, _d, _d, _d, _i, _i]),
     ("adf_fgs_destroy", None, [_vp]),
     ("adf_fgs_filter_host", _i, [_vp, _vp, _pd, _vp, _pd, _i, _i]),

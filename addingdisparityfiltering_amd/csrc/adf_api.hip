@@ -110,6 +110,42 @@ struct Lut {
     }
 };
 
+// Per-launch HIP-event timing (adf_wls_profile_*).  Events are pooled and reused.
+enum KClass { K_FILL = 0, K_WEIGHTS, K_DISC, K_LRC, K_PROLOGUE, K_PASS_H, K_PASS_V, K_PASS_V_LAST, K_COUNT };
+static const char* const kclass_names[K_COUNT] = {"fill_outside", "weights", "discontinuity", "lrc_prologue",
+                                                  "plain_prologue", "pass_h", "pass_v", "pass_v_last"};
+struct Profiler {
+    bool on = false;
+    struct Rec { int cls; hipEvent_t a, b; double alg, moved; };
+    std::vector<Rec> recs;
+    std::vector<hipEvent_t> pool;
+    hipEvent_t get()
+    {
+        if (!pool.empty()) { hipEvent_t e = pool.back(); pool.pop_back(); return e; }
+        hipEvent_t e = nullptr;
+        if (hipEventCreate(&e) != hipSuccess) return nullptr;
+        return e;
+    }
+    void clear() { for (auto& r : recs) { pool.push_back(r.a); pool.push_back(r.b); } recs.clear(); }
+    void destroy() { clear(); for (auto e : pool) hipEventDestroy(e); pool.clear(); }
+};
+// Brackets one launch: start event in the constructor, stop event in the destructor.
+struct ProfScope {
+    Profiler* p; hipStream_t st; Profiler::Rec r{};
+    ProfScope(Profiler* prof, int cls, double alg, double moved, hipStream_t s) : p(prof && prof->on ? prof : nullptr), st(s)
+    {
+        if (!p) return;
+        r.cls = cls; r.alg = alg; r.moved = moved; r.a = p->get(); r.b = p->get();
+        if (r.a) hipEventRecord(r.a, st);
+    }
+    ~ProfScope()
+    {
+        if (!p) return;
+        if (r.b) hipEventRecord(r.b, st);
+        if (r.a && r.b) p->recs.push_back(r);
+    }
+};
+
 // The six (2*num_iter) solve passes of FGS.cpp:207-212 on planes already resident on the device.
 // `A` holds the right-hand sides in the orientation the first (horizontal) pass wants.
 struct SolvePlanes {
@@ -124,16 +160,22 @@ struct FinalOut {
 };
 
 static int run_passes_exact(const Geom& g, const SolvePlanes& p, int n_rhs, float lambda, float atten,
-                            int num_iter, const FinalOut& fo, int n_pairs, hipStream_t st)
+                            int num_iter, const FinalOut& fo, int n_pairs, hipStream_t st, Profiler* prof = nullptr)
 {
     float lam = lambda;
+    const double px = (double)g.rw * g.rh * n_pairs;
+    const double alg = (4.0 + 8.0 * n_rhs) * px;      // read weight + R rhs, write R rhs
+    const double moved = (12.0 + 16.0 * n_rhs) * px;  // exact solver: D and the eliminated rhs round-trip
     for (int it = 0; it < num_iter; it++) {
         PassArgs h{};
         h.C = p.CH; h.U0 = p.A0; h.U1 = p.A1; h.D = p.D; h.F0 = p.F0; h.F1 = p.F1;
         h.O0 = p.B0; h.O1 = p.B1;
         h.nscan = g.rh; h.len = g.rw; h.pitch_in = g.ph; h.pitch_out = g.pw;
         h.plane = g.plane; h.lambda = lam;
-        HIP_TRY(launch_exact_pass(h, n_rhs, EPI_PLANES, n_pairs, st));   // FGS.cpp:209
+        {
+            ProfScope ps(prof, K_PASS_H, alg, moved, st);
+            HIP_TRY(launch_exact_pass(h, n_rhs, EPI_PLANES, n_pairs, st)); // FGS.cpp:209
+        }
 
         const bool last = (it == num_iter - 1);
         PassArgs v{};
@@ -145,7 +187,13 @@ static int run_passes_exact(const Geom& g, const SolvePlanes& p, int n_rhs, floa
             v.out = fo.out; v.out_stride = fo.stride; v.out_pair_stride = fo.pair_stride;
             v.out_x0 = fo.x0; v.out_y0 = fo.y0; v.out_cn = fo.cn; v.out_c = fo.c;
         }
-        HIP_TRY(launch_exact_pass(v, n_rhs, last ? fo.epilogue : EPI_PLANES, n_pairs, st)); // FGS.cpp:210
+        {
+            // the fused epilogue writes 2 (int16) instead of 4R bytes per pixel
+            const double out_b = last ? (fo.epilogue == EPI_F32 ? 4.0 : fo.epilogue == EPI_U8 ? 1.0 : 2.0) * px : 4.0 * n_rhs * px;
+            ProfScope ps(prof, last ? K_PASS_V_LAST : K_PASS_V, (4.0 + 4.0 * n_rhs) * px + out_b,
+                         (12.0 + 12.0 * n_rhs) * px + out_b, st);
+            HIP_TRY(launch_exact_pass(v, n_rhs, last ? fo.epilogue : EPI_PLANES, n_pairs, st)); // FGS.cpp:210
+        }
         lam *= atten;                                                      // FGS.cpp:211 (float)
     }
     return ADF_OK;
@@ -175,6 +223,7 @@ struct adf_wls {
     DevBuf conf;  // confidence maps of the last call (n_pairs full frames)
     DevBuf stage; // host-pointer path staging
     size_t ws_limit = (size_t)64 << 30;
+    Profiler prof;
 };
 
 extern "C" int adf_wls_create(adf_wls_t** out, int use_confidence, int l, int r, int t, int b, int min_disp)
@@ -204,6 +253,7 @@ extern "C" void adf_wls_destroy(adf_wls_t* h)
     if (!h) return;
     DeviceScope ds(h->device);
     h->lut.dev.release(); h->ws.release(); h->conf.release(); h->stage.release();
+    h->prof.destroy();
     delete h;
 }
 
@@ -321,32 +371,51 @@ extern "C" int adf_wls_filter_device(adf_wls_t* h, int n_pairs,
         const uint8_t* gv = view + (ptrdiff_t)first * psG;
         int16_t* o = (int16_t*)((char*)out + (ptrdiff_t)first * psO);
 
+        const double F = (double)g.frame * n, P = (double)g.rw * g.rh * n;
+        Profiler* prof = &h->prof;
         FillArgs fa{o, sO, psO, g, (int16_t)(16 * (h->min_disp - 1))};    // DF.cpp:254,284
-        HIP_TRY(launch_fill_outside(fa, n, st));
-
+        {
+            ProfScope ps(prof, K_FILL, 2.0 * (F - P), 2.0 * (F - P), st);
+            HIP_TRY(launch_fill_outside(fa, n, st));
+        }
         WeightArgs wa{gv, sG, psG, gch, (const float*)h->lut.dev.p, p.CH, p.CV, ORIENT_T, ORIENT_N, g};
-        HIP_TRY(launch_weights(wa, n, st));                                // FGS.cpp:163-172
+        {
+            ProfScope ps(prof, K_WEIGHTS, (gch + 8.0) * P, (gch + 8.0) * P, st);
+            HIP_TRY(launch_weights(wa, n, st));                            // FGS.cpp:163-172
+        }
 
         if (conf) {
             const int16_t* dRp = (const int16_t*)((const char*)dispR + (ptrdiff_t)first * psR);
             const int rrx = W - (roi.x + roi.width);                       // DF.cpp:202
             DiscArgs da{dL, sL, psL, roi.x, roi.y, roi.width, roi.height, h->disc_radius, h->roll_off,
                         cL, W, g.frame};
-            HIP_TRY(launch_discontinuity(da, n, st));                      // DF.cpp:204
+            {   // reads the int16 ROI, writes the float map (the maps themselves are not algorithmic I/O)
+                ProfScope ps(prof, K_DISC, 2.0 * P, 6.0 * P, st);
+                HIP_TRY(launch_discontinuity(da, n, st));                  // DF.cpp:204
+            }
             DiscArgs db{dRp, sR, psR, rrx, roi.y, roi.width, roi.height, h->disc_radius, h->roll_off,
                         cR, W, g.frame};
-            HIP_TRY(launch_discontinuity(db, n, st));
+            {
+                ProfScope ps(prof, K_DISC, 2.0 * P, 6.0 * P, st);
+                HIP_TRY(launch_discontinuity(db, n, st));
+            }
             LrcArgs la{dL, sL, psL, dRp, sR, psR, cL, cR, (float*)h->conf.p + (size_t)first * g.frame,
                        p.A0, p.A1, g, rrx, (int)(1.0f * h->lrc_thresh) /* DF.cpp:318 */, ORIENT_T};
-            HIP_TRY(launch_lrc_prologue(la, n, st));                       // DF.cpp:208-209,288-290
+            {   // alg: confidence map out (4F) + the two rhs planes (8P); moved adds dL,dR,cL,cR reads
+                ProfScope ps(prof, K_LRC, 4.0 * F + 8.0 * P, 4.0 * F + 20.0 * P, st);
+                HIP_TRY(launch_lrc_prologue(la, n, st));                   // DF.cpp:208-209,288-290
+            }
             FinalOut fo{EPI_WLS_CONF, o, sO, psO, roi.x, roi.y, 1, 0};
-            if ((rc = run_passes_exact(g, p, 2, (float)h->lambda, (float)h->atten, h->num_iter, fo, n, st)))
+            if ((rc = run_passes_exact(g, p, 2, (float)h->lambda, (float)h->atten, h->num_iter, fo, n, st, prof)))
                 return rc;                                                 // DF.cpp:292-296
         } else {
             PlainPrologueArgs pa{dL, sL, psL, ADF_16S, 1, 0, p.A0, g, ORIENT_T};
-            HIP_TRY(launch_plain_prologue(pa, n, st));                     // FGS.cpp:203-205
+            {
+                ProfScope ps(prof, K_PROLOGUE, 6.0 * P, 6.0 * P, st);
+                HIP_TRY(launch_plain_prologue(pa, n, st));                 // FGS.cpp:203-205
+            }
             FinalOut fo{EPI_I16, o, sO, psO, roi.x, roi.y, 1, 0};
-            if ((rc = run_passes_exact(g, p, 1, (float)h->lambda, (float)h->atten, h->num_iter, fo, n, st)))
+            if ((rc = run_passes_exact(g, p, 1, (float)h->lambda, (float)h->atten, h->num_iter, fo, n, st, prof)))
                 return rc;                                                 // DF.cpp:257-258
         }
     }
@@ -395,6 +464,36 @@ extern "C" int adf_wls_filter_host(adf_wls_t* h, int n_pairs,
         HIP_TRY(hipMemcpy2DAsync((char*)out + (ptrdiff_t)k * psO, sO, od + k * dpad, (size_t)W * 2,
                                  (size_t)W * 2, H, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
+    return ADF_OK;
+}
+
+extern "C" int adf_wls_profile_enable(adf_wls_t* h, int on)
+{
+    NEED_HANDLE(h);
+    DeviceScope ds(h->device);
+    h->prof.clear();
+    h->prof.on = on != 0;
+    return ADF_OK;
+}
+
+extern "C" int adf_wls_profile_read(adf_wls_t* h, adf_kernel_time* out, int capacity, int* count)
+{
+    NEED_HANDLE(h);
+    if (!out || !count || capacity < 1) return fail(ADF_EBADARG, "adf_wls_profile_read: bad output buffer");
+    DeviceScope ds(h->device);
+    adf_kernel_time acc[K_COUNT];
+    memset(acc, 0, sizeof(acc));
+    for (int k = 0; k < K_COUNT; k++) snprintf(acc[k].name, sizeof(acc[k].name), "%s", kclass_names[k]);
+    for (auto& r : h->prof.recs) {
+        HIP_TRY(hipEventSynchronize(r.b));
+        float ms = 0.0f;
+        HIP_TRY(hipEventElapsedTime(&ms, r.a, r.b));
+        acc[r.cls].launches++; acc[r.cls].total_ms += ms; acc[r.cls].alg_bytes += r.alg; acc[r.cls].moved_bytes += r.moved;
+    }
+    int n = 0;
+    for (int k = 0; k < K_COUNT && n < capacity; k++)
+        if (acc[k].launches) out[n++] = acc[k];
+    *count = n;
     return ADF_OK;
 }
 

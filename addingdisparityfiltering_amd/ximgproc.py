@@ -177,6 +177,19 @@ class DisparityWLSFilter(DisparityFilter):
     def getSolver(self):
         return self._geti(_lib.lib().adf_wls_get_solver)
 
+    def enableProfiling(self, on=True):
+        """Bracket every kernel launch with HIP events on the caller's stream (measurement hook)."""
+        _lib.check(_lib.lib().adf_wls_profile_enable(self._h, int(bool(on))))
+
+    def readProfile(self):
+        """{kernel class: dict(launches, total_ms, alg_bytes, moved_bytes)} since enableProfiling()."""
+        buf = (_lib.KernelTime * 16)()
+        n = C.c_int()
+        _lib.check(_lib.lib().adf_wls_profile_read(self._h, buf, 16, C.byref(n)))
+        return {buf[k].name.decode(): dict(launches=buf[k].launches, total_ms=buf[k].total_ms,
+                                           alg_bytes=buf[k].alg_bytes, moved_bytes=buf[k].moved_bytes)
+                for k in range(n.value)}
+
     def workspaceBytes(self):
         return int(_lib.lib().adf_wls_workspace_bytes(self._h))
 

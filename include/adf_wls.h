@@ -131,6 +131,21 @@ int adf_wls_sync(adf_wls_t* h, void* stream);
 /* Bytes of device workspace currently owned by the handle. */
 size_t adf_wls_workspace_bytes(const adf_wls_t* h);
 
+/* Measurement hook (no counterpart in the reference, which times filter() from outside with
+ * getTickCount: samples/disparity_filtering.cpp:186-191).  While enabled, every kernel launch of
+ * adf_wls_filter_device is bracketed by HIP events recorded on the caller's stream;
+ * adf_wls_profile_read waits for them and returns per-kernel-class launch counts, summed durations
+ * and the algorithmic bytes those launches moved (SURVEY.md 8d figures). */
+typedef struct adf_kernel_time {
+    char name[48];      /* kernel class, e.g. "pass_h", "pass_v", "weights"            */
+    int launches;
+    double total_ms;    /* sum of event-to-event durations                               */
+    double alg_bytes;   /* algorithmic bytes summed over the launches                    */
+    double moved_bytes; /* bytes this implementation reads+writes, by construction       */
+} adf_kernel_time;
+int adf_wls_profile_enable(adf_wls_t* h, int on); /* also clears what was collected */
+int adf_wls_profile_read(adf_wls_t* h, adf_kernel_time* out, int capacity, int* count);
+
 /* ---------------- FastGlobalSmootherFilter ---------------- */
 
 /* createFastGlobalSmootherFilter(guide, lambda, sigma_color, lambda_attenuation,
