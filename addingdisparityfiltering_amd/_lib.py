@@ -52,6 +52,7 @@ SYMBOLS = [
     ("adf_wls_set_fgs_params", _i, [_vp, _d, _i]),
     ("adf_wls_set_solver", _i, [_vp, _i]),
     ("adf_wls_get_solver", _i, [_vp, C.POINTER(_i)]),
+    ("adf_wls_get_last_solver", _i, [_vp, C.POINTER(_i)]),
     ("adf_wls_filter_device", _i, _FILTER_DEV),
     ("adf_wls_filter_host", _i, _FILTER_DEV[:-1]),
     ("adf_wls_get_confidence_device", _i, [_vp, _i, _vp, _pd, _vp]),

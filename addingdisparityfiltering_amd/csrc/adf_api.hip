@@ -199,6 +199,45 @@ static int run_passes_exact(const Geom& g, const SolvePlanes& p, int n_rhs, floa
     return ADF_OK;
 }
 
+// Same six passes with the on-chip partitioned solver: row-major planes, in place, algorithmic traffic.
+static int run_passes_wave(const Geom& g, const SolvePlanes& p, int n_rhs, float lambda, float atten,
+                           int num_iter, const FinalOut& fo, int n_pairs, hipStream_t st, Profiler* prof = nullptr)
+{
+    float lam = lambda;
+    const double px = (double)g.rw * g.rh * n_pairs;
+    const double alg = (4.0 + 8.0 * n_rhs) * px;
+    for (int it = 0; it < num_iter; it++) {
+        WavePassArgs h{};
+        h.C = p.CH; h.U0 = p.A0; h.U1 = p.A1;
+        h.nscan = g.rh; h.len = g.rw; h.pitch = g.pw; h.plane = g.plane; h.lambda = lam;
+        {
+            ProfScope ps(prof, K_PASS_H, alg, alg, st);
+            HIP_TRY(launch_wave_hpass(h, n_rhs, n_pairs, st));             // FGS.cpp:209
+        }
+        const bool last = (it == num_iter - 1);
+        WavePassArgs v{};
+        v.C = p.CV; v.U0 = p.A0; v.U1 = p.A1;
+        v.nscan = g.rw; v.len = g.rh; v.pitch = g.pw; v.plane = g.plane; v.lambda = lam;
+        if (last) {
+            v.out = fo.out; v.out_stride = fo.stride; v.out_pair_stride = fo.pair_stride;
+            v.out_x0 = fo.x0; v.out_y0 = fo.y0; v.out_cn = fo.cn; v.out_c = fo.c;
+        }
+        {
+            const double out_b = last ? (fo.epilogue == EPI_F32 ? 4.0 : fo.epilogue == EPI_U8 ? 1.0 : 2.0) * px : 4.0 * n_rhs * px;
+            const double bytes = (4.0 + 4.0 * n_rhs) * px + out_b;
+            ProfScope ps(prof, last ? K_PASS_V_LAST : K_PASS_V, bytes, bytes, st);
+            HIP_TRY(launch_wave_vpass(v, n_rhs, last ? fo.epilogue : EPI_PLANES, n_pairs, st)); // FGS.cpp:210
+        }
+        lam *= atten;                                                      // FGS.cpp:211 (float)
+    }
+    return ADF_OK;
+}
+
+static bool wave_fits(const Geom& g)
+{
+    return g.rw >= 2 && g.rh >= 2 && g.rw <= wave_max_row_len() && g.rh <= wave_max_col_len();
+}
+
 // ----------------------------------------------------------------------------------------------
 // DisparityWLSFilter
 // ----------------------------------------------------------------------------------------------
@@ -214,6 +253,7 @@ struct adf_wls {
     // EF.hpp:393 defaults used by DF.cpp:292
     double atten = 0.25; int num_iter = 3;
     int solver = ADF_SOLVER_EXACT;
+    int last_solver = ADF_SOLVER_EXACT;
     // state of the last call
     adf_rect roi{0, 0, 0, 0};
     int last_W = 0, last_H = 0, last_pairs = 0;
@@ -224,6 +264,9 @@ struct adf_wls {
     DevBuf stage; // host-pointer path staging
     size_t ws_limit = (size_t)64 << 30;
     Profiler prof;
+    // (geometry, solver) the workspace planes were last laid out for; a change re-zeroes them so that
+    // pitch padding is zero again (the wave solver treats it as identity rows without masking)
+    long long ws_sig[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 };
 
 extern "C" int adf_wls_create(adf_wls_t** out, int use_confidence, int l, int r, int t, int b, int min_disp)
@@ -279,11 +322,12 @@ extern "C" int adf_wls_set_fgs_params(adf_wls_t* h, double atten, int num_iter)
 extern "C" int adf_wls_set_solver(adf_wls_t* h, int solver)
 {
     NEED_HANDLE(h);
-    if (solver != ADF_SOLVER_EXACT) return fail(ADF_EBADARG, "solver %d not available in this build", solver);
+    if (solver != ADF_SOLVER_EXACT && solver != ADF_SOLVER_WAVE) return fail(ADF_EBADARG, "unknown solver %d", solver);
     h->solver = solver;
     return ADF_OK;
 }
 extern "C" int adf_wls_get_solver(const adf_wls_t* h, int* v) { NEED_HANDLE(h); if (v) *v = h->solver; return ADF_OK; }
+extern "C" int adf_wls_get_last_solver(const adf_wls_t* h, int* v) { NEED_HANDLE(h); if (v) *v = h->last_solver; return ADF_OK; }
 
 extern "C" int adf_wls_get_roi(const adf_wls_t* h, adf_rect* roi) { NEED_HANDLE(h); if (roi) *roi = h->roi; return ADF_OK; }
 extern "C" size_t adf_wls_workspace_bytes(const adf_wls_t* h)
@@ -299,10 +343,11 @@ extern "C" int adf_wls_sync(adf_wls_t* h, void* stream)
     return ADF_OK;
 }
 
-static size_t wls_pair_ws_bytes(const Geom& g, bool conf)
+static size_t wls_pair_ws_bytes(const Geom& g, bool conf, bool wave)
 {
-    // ROI planes: CH CV D F0 A0 B0 (+ F1 A1 B1 with confidence); full frames: cL cR
-    size_t planes = conf ? 9 : 6;
+    // exact: ROI planes CH CV D F0 A0 B0 (+ F1 A1 B1 with confidence); wave: CH CV A0 (+ A1), in place
+    // full frames: cL cR (confidence only)
+    size_t planes = wave ? (conf ? 4 : 3) : (conf ? 9 : 6);
     return planes * g.plane * sizeof(float) + (conf ? 2 * g.frame * sizeof(float) : 0);
 }
 
@@ -346,24 +391,37 @@ extern "C" int adf_wls_filter_device(adf_wls_t* h, int n_pairs,
     int rc = h->lut.ensure((float)h->sigma_color, st);
     if (rc) return rc;
     const bool conf = h->use_confidence;
-    const size_t per_pair = wls_pair_ws_bytes(g, conf);
+    // sizes outside the register-resident kernels' range fall back to the exact solver
+    const bool wave = h->solver == ADF_SOLVER_WAVE && wave_fits(g);
+    h->last_solver = wave ? ADF_SOLVER_WAVE : ADF_SOLVER_EXACT;
+    const size_t per_pair = wls_pair_ws_bytes(g, conf, wave);
     int chunk = (int)(h->ws_limit / per_pair);
     if (chunk < 1) chunk = 1;
     if (chunk > n_pairs) chunk = n_pairs;
     if ((rc = h->ws.reserve(per_pair * (size_t)chunk, st))) return rc;
     if (conf && (rc = h->conf.reserve(g.frame * sizeof(float) * (size_t)n_pairs, st))) return rc;
 
+    {
+        const long long sig[8] = {W, H, roi.x, roi.y, roi.width, roi.height, (long long)wave * 2 + conf, chunk};
+        if (memcmp(sig, h->ws_sig, sizeof(sig)) != 0) {
+            HIP_TRY(hipMemsetAsync(h->ws.p, 0, h->ws.bytes, st));
+            memcpy(h->ws_sig, sig, sizeof(sig));
+        }
+    }
     // carve the workspace
     float* base = (float*)h->ws.p;
     auto take = [&](size_t elems) { float* p = base; base += elems * (size_t)chunk; return p; };
     SolvePlanes p{};
-    p.CH = take(g.plane); p.CV = take(g.plane); p.D = take(g.plane);
-    p.F0 = take(g.plane); p.A0 = take(g.plane); p.B0 = take(g.plane);
+    p.CH = take(g.plane); p.CV = take(g.plane); p.A0 = take(g.plane);
+    if (!wave) { p.D = take(g.plane); p.F0 = take(g.plane); p.B0 = take(g.plane); }
     float *cL = nullptr, *cR = nullptr;
     if (conf) {
-        p.F1 = take(g.plane); p.A1 = take(g.plane); p.B1 = take(g.plane);
+        p.A1 = take(g.plane);
+        if (!wave) { p.F1 = take(g.plane); p.B1 = take(g.plane); }
         cL = take(g.frame); cR = take(g.frame);
     }
+    // exact: the horizontal pass wants the row index fastest (T); wave: everything row-major (N)
+    const int orient_h = wave ? ORIENT_N : ORIENT_T;
 
     for (int first = 0; first < n_pairs; first += chunk) {
         const int n = (n_pairs - first < chunk) ? n_pairs - first : chunk;
@@ -378,7 +436,7 @@ extern "C" int adf_wls_filter_device(adf_wls_t* h, int n_pairs,
             ProfScope ps(prof, K_FILL, 2.0 * (F - P), 2.0 * (F - P), st);
             HIP_TRY(launch_fill_outside(fa, n, st));
         }
-        WeightArgs wa{gv, sG, psG, gch, (const float*)h->lut.dev.p, p.CH, p.CV, ORIENT_T, ORIENT_N, g};
+        WeightArgs wa{gv, sG, psG, gch, (const float*)h->lut.dev.p, p.CH, p.CV, orient_h, ORIENT_N, g};
         {
             ProfScope ps(prof, K_WEIGHTS, (gch + 8.0) * P, (gch + 8.0) * P, st);
             HIP_TRY(launch_weights(wa, n, st));                            // FGS.cpp:163-172
@@ -400,23 +458,25 @@ extern "C" int adf_wls_filter_device(adf_wls_t* h, int n_pairs,
                 HIP_TRY(launch_discontinuity(db, n, st));
             }
             LrcArgs la{dL, sL, psL, dRp, sR, psR, cL, cR, (float*)h->conf.p + (size_t)first * g.frame,
-                       p.A0, p.A1, g, rrx, (int)(1.0f * h->lrc_thresh) /* DF.cpp:318 */, ORIENT_T};
+                       p.A0, p.A1, g, rrx, (int)(1.0f * h->lrc_thresh) /* DF.cpp:318 */, orient_h};
             {   // alg: confidence map out (4F) + the two rhs planes (8P); moved adds dL,dR,cL,cR reads
                 ProfScope ps(prof, K_LRC, 4.0 * F + 8.0 * P, 4.0 * F + 20.0 * P, st);
                 HIP_TRY(launch_lrc_prologue(la, n, st));                   // DF.cpp:208-209,288-290
             }
             FinalOut fo{EPI_WLS_CONF, o, sO, psO, roi.x, roi.y, 1, 0};
-            if ((rc = run_passes_exact(g, p, 2, (float)h->lambda, (float)h->atten, h->num_iter, fo, n, st, prof)))
-                return rc;                                                 // DF.cpp:292-296
+            rc = wave ? run_passes_wave(g, p, 2, (float)h->lambda, (float)h->atten, h->num_iter, fo, n, st, prof)
+                      : run_passes_exact(g, p, 2, (float)h->lambda, (float)h->atten, h->num_iter, fo, n, st, prof);
+            if (rc) return rc;                                             // DF.cpp:292-296
         } else {
-            PlainPrologueArgs pa{dL, sL, psL, ADF_16S, 1, 0, p.A0, g, ORIENT_T};
+            PlainPrologueArgs pa{dL, sL, psL, ADF_16S, 1, 0, p.A0, g, orient_h};
             {
                 ProfScope ps(prof, K_PROLOGUE, 6.0 * P, 6.0 * P, st);
                 HIP_TRY(launch_plain_prologue(pa, n, st));                 // FGS.cpp:203-205
             }
             FinalOut fo{EPI_I16, o, sO, psO, roi.x, roi.y, 1, 0};
-            if ((rc = run_passes_exact(g, p, 1, (float)h->lambda, (float)h->atten, h->num_iter, fo, n, st, prof)))
-                return rc;                                                 // DF.cpp:257-258
+            rc = wave ? run_passes_wave(g, p, 1, (float)h->lambda, (float)h->atten, h->num_iter, fo, n, st, prof)
+                      : run_passes_exact(g, p, 1, (float)h->lambda, (float)h->atten, h->num_iter, fo, n, st, prof);
+            if (rc) return rc;                                             // DF.cpp:257-258
         }
     }
     return ADF_OK;
@@ -549,7 +609,7 @@ extern "C" int adf_fgs_create(adf_fgs_t** out, const uint8_t* guide, ptrdiff_t g
     if (lambda < 0 || sigma_color < 0 || num_iter < 1) return fail(ADF_EBADARG, "lambda>=0, sigma_color>=0, num_iter>=1 required");
     if (gch != 1 && gch != 3) return fail(ADF_EBADARG, "guide must be CV_8UC1 or CV_8UC3");
     if (gstride < (ptrdiff_t)w * gch) return fail(ADF_ESIZE, "guide stride smaller than a row");
-    if (solver != ADF_SOLVER_EXACT) return fail(ADF_EBADARG, "solver %d not available in this build", solver);
+    if (solver != ADF_SOLVER_EXACT && solver != ADF_SOLVER_WAVE) return fail(ADF_EBADARG, "unknown solver %d", solver);
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return fail(ADF_ENODEV, "adf_fgs_create: no HIP device visible");
     adf_fgs* f = new (std::nothrow) adf_fgs();
@@ -557,8 +617,9 @@ extern "C" int adf_fgs_create(adf_fgs_t** out, const uint8_t* guide, ptrdiff_t g
     hipGetDevice(&f->device);
     f->w = w; f->h = hgt;
     f->lambda = (float)lambda; f->sigma = (float)sigma_color; f->atten = (float)atten; // FGS.cpp:145-147
-    f->num_iter = num_iter; f->solver = solver;
+    f->num_iter = num_iter;
     f->g = make_geom(w, hgt, 0, 0, w, hgt);
+    f->solver = (solver == ADF_SOLVER_WAVE && wave_fits(f->g)) ? ADF_SOLVER_WAVE : ADF_SOLVER_EXACT;
     hipStream_t st = nullptr;
     int rc = f->lut.ensure(f->sigma, st);
     if (!rc) rc = f->planes.reserve(6 * f->g.plane * sizeof(float), st);
@@ -569,7 +630,7 @@ extern "C" int adf_fgs_create(adf_fgs_t** out, const uint8_t* guide, ptrdiff_t g
     if (e == hipSuccess) {
         float* base = (float*)f->planes.p;
         WeightArgs wa{(const uint8_t*)f->io.p, (ptrdiff_t)w * gch, 0, gch, (const float*)f->lut.dev.p,
-                      base, base + f->g.plane, ORIENT_T, ORIENT_N, f->g};
+                      base, base + f->g.plane, f->solver == ADF_SOLVER_WAVE ? ORIENT_N : ORIENT_T, ORIENT_N, f->g};
         e = launch_weights(wa, 1, st);
     }
     if (e == hipSuccess) e = hipStreamSynchronize(st);
@@ -609,12 +670,14 @@ extern "C" int adf_fgs_filter_host(adf_fgs_t* f, const void* src, ptrdiff_t sstr
     p.A0 = base + 4 * g.plane; p.B0 = base + 5 * g.plane;
     const int epi = depth == ADF_8U ? EPI_U8 : depth == ADF_16S ? EPI_I16 : EPI_F32;
     for (int c = 0; c < channels; c++) { // FGS.cpp:200-221: channels filtered one by one
-        PlainPrologueArgs pa{img, (ptrdiff_t)rowb, 0, depth, channels, c, p.A0, g, ORIENT_T};
+        const bool wave = f->solver == ADF_SOLVER_WAVE;
+        PlainPrologueArgs pa{img, (ptrdiff_t)rowb, 0, depth, channels, c, p.A0, g, wave ? ORIENT_N : ORIENT_T};
         HIP_TRY(launch_plain_prologue(pa, 1, st));
         // the epilogue of channel c overwrites only channel c of the staged image, which later
         // channels never read (they read their own channel), so filtering in place is safe
         FinalOut fo{epi, img, (ptrdiff_t)rowb, 0, 0, 0, channels, c};
-        int rc = run_passes_exact(g, p, 1, f->lambda, f->atten, f->num_iter, fo, 1, st);
+        int rc = wave ? run_passes_wave(g, p, 1, f->lambda, f->atten, f->num_iter, fo, 1, st)
+                      : run_passes_exact(g, p, 1, f->lambda, f->atten, f->num_iter, fo, 1, st);
         if (rc) return rc;
     }
     HIP_TRY(hipMemcpy2DAsync(dst, dstride, img, rowb, rowb, f->h, hipMemcpyDeviceToHost, st));

@@ -85,6 +85,18 @@ struct PassArgs {
     float lambda;
 };
 
+// One pass of the on-chip partitioned solver (fgs_wave.hip).  Planes are row-major [rh][pitch] and
+// are solved IN PLACE; horizontal: nscan = rows, len = row length; vertical: nscan = columns,
+// len = column length.  The last vertical pass may fuse an epilogue and write `out` instead.
+struct WavePassArgs {
+    const float* C; float* U0; float* U1;
+    void* out; ptrdiff_t out_stride, out_pair_stride;
+    int out_x0, out_y0, out_cn, out_c;
+    int nscan, len, pitch;
+    size_t plane;
+    float lambda;
+};
+
 // Launchers (defined in the .hip files).  All are asynchronous on `st`.
 hipError_t launch_discontinuity(const DiscArgs& a, int n_pairs, hipStream_t st);
 hipError_t launch_lrc_prologue(const LrcArgs& a, int n_pairs, hipStream_t st);
@@ -92,6 +104,10 @@ hipError_t launch_plain_prologue(const PlainPrologueArgs& a, int n_pairs, hipStr
 hipError_t launch_weights(const WeightArgs& a, int n_pairs, hipStream_t st);
 hipError_t launch_fill_outside(const FillArgs& a, int n_pairs, hipStream_t st);
 hipError_t launch_exact_pass(const PassArgs& a, int n_rhs, int epilogue, int n_pairs, hipStream_t st);
+hipError_t launch_wave_hpass(const WavePassArgs& a, int n_rhs, int n_pairs, hipStream_t st);
+hipError_t launch_wave_vpass(const WavePassArgs& a, int n_rhs, int epilogue, int n_pairs, hipStream_t st);
+int wave_max_row_len();
+int wave_max_col_len();
 // largest depth-discontinuity radius the tile kernel supports (LDS bound)
 int max_disc_radius();
 

@@ -1,0 +1,221 @@
+// fgs_wave_common.h -- on-chip partitioned Thomas solve (ADF_SOLVER_WAVE).
+//
+// Same tridiagonal systems as FastGlobalSmootherFilterImpl::process_row / VerticalPass_ParBody
+// (FGS.cpp:439-464, 484-584):  a_j x_{j-1} + b_j x_j + c_j x_{j+1} = f_j  with  c_j = lambda*C[j],
+// a_j = c_{j-1}, b_j = 1 - a_j - c_j -- but solved so that every scanline stays on chip and HBM sees
+// only the algorithmic traffic (read C and the R right-hand sides, write the R solutions: 4+8R bytes
+// per pixel instead of the 12+16R of a lane-per-scanline sweep that must spill D and the eliminated
+// right-hand sides).
+//
+// A scanline is cut into 64 chunks of M elements.  The last element of each chunk is a separator:
+//   phase 1  two running sweeps over the chunk interior (left->right LU, right->left UL) give, with
+//            O(1) state, how the interior's two end elements depend on the neighbouring separators:
+//            x_first = GS - PS*xL - QS*xR,  x_last = GE - PE*xL - QE*xR;
+//   reduce   the 64 separator equations form a tridiagonal system (alpha,beta,gamma,phi) solved by
+//            parallel cyclic reduction across the 64 lanes of a wavefront (6 shuffle steps);
+//   phase 2  with xL, xR known, a plain Thomas solve of the interior held entirely in registers.
+// The matrix is strictly diagonally dominant (b = 1 + |a| + |c|), so every step is stable without
+// pivoting.  Arithmetic is re-associated (FMA, v_rcp + one Newton step) => results differ from the
+// scalar order in the last bits; the tests hold them to the reference's own reproducibility bar
+// (<=1 LSB of the CV_16S output, mean <=1/256 LSB: test_disparity_wls_filter.cpp:104-105).
+//
+//   horizontal pass: one wavefront per image row; lane l owns columns [l*M, l*M+M); the row goes
+//                    HBM -> (coalesced 16 B/lane) -> LDS -> (chunk per lane) -> registers and back.
+//   vertical pass:   one 512-thread workgroup per strip of 16 columns; thread (chunk, column pair)
+//                    owns M rows of 2 columns; the whole strip (16 x H x 3 floats) lives in the CU's
+//                    register file; neighbour / separator exchange through LDS; each row of the strip
+//                    is a 64-byte segment (the other half of the line is served from L2/MALL to the
+//                    neighbouring strip).
+// All planes are row-major [rh][pw]; nothing is transposed and both passes work in place.
+#pragma once
+#include "adf_internal.h"
+
+namespace adf {
+namespace wave {
+
+__device__ __forceinline__ float rcp_nr(float x)
+{
+    float r = __builtin_amdgcn_rcpf(x);
+    return __builtin_fmaf(__builtin_fmaf(-x, r, 1.0f), r, r);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Chunk kernels shared by both passes.  c[] is already multiplied by lambda; element M-1 is the
+// separator, elements 0..M-2 the interior; a_s is c of the element before the chunk (0 for chunk 0).
+// ---------------------------------------------------------------------------------------------
+template <int R>
+struct Boundary { float GS0, GS1, PS, QS, GE0, GE1, PE, QE; };
+
+// The sweeps below are serial recurrences; hipcc's scheduler, left alone, hoists every
+// chain-independent temporary (b_i = 1 - a_i - c_i, c_i^2, negations) of a fully unrolled sweep to the
+// front and keeps them alive -- several extra registers per element, i.e. spills at the chunk lengths
+// a 4K scanline needs.  A scheduling barrier per element keeps the source order (temporaries die
+// within their own step), and an empty asm on c[] keeps temporaries from being shared between sweeps.
+#define ADF_STEP_FENCE() __builtin_amdgcn_sched_barrier(0)
+
+template <int M>
+__device__ __forceinline__ void launder(float (&v)[M])
+{
+#pragma unroll
+    for (int i = 0; i < M; i++) asm volatile("" : "+v"(v[i]));
+}
+
+// Phase 1 for NC independent chunks (columns) interleaved: boundary coefficients with O(1) state.
+template <int M, int R, int NC>
+__device__ __forceinline__ void chunk_boundary(float (&c)[NC][M], const float (&f0)[NC][M], const float (&f1)[NC][M],
+                                               const float (&a_s)[NC], Boundary<R> (&o)[NC])
+{
+    // left -> right: x_i + D_i x_{i+1} = g_i - p_i xL
+    {
+        float D[NC], g0[NC], g1[NC], p[NC];
+#pragma unroll
+        for (int e = 0; e < NC; e++) {
+            const float a = a_s[e];
+            const float r = rcp_nr((1.0f - a) - c[e][0]);
+            D[e] = c[e][0] * r; g0[e] = f0[e][0] * r; g1[e] = (R > 1) ? f1[e][0] * r : 0.0f; p[e] = a * r;
+        }
+#pragma unroll
+        for (int i = 1; i <= M - 2; i++) {
+#pragma unroll
+            for (int e = 0; e < NC; e++) {
+                const float a = c[e][i - 1];
+                const float b = (1.0f - a) - c[e][i];
+                const float r = rcp_nr(__builtin_fmaf(-a, D[e], b));
+                D[e] = c[e][i] * r;
+                g0[e] = __builtin_fmaf(-a, g0[e], f0[e][i]) * r;
+                if (R > 1) g1[e] = __builtin_fmaf(-a, g1[e], f1[e][i]) * r;
+                p[e] = (-a * p[e]) * r;
+                asm volatile("" : "+v"(p[e])); // p feeds nothing until the end: keep its chain in step
+            }
+            ADF_STEP_FENCE();
+        }
+#pragma unroll
+        for (int e = 0; e < NC; e++) { o[e].GE0 = g0[e]; o[e].GE1 = g1[e]; o[e].PE = p[e]; o[e].QE = D[e]; }
+    }
+#pragma unroll
+    for (int e = 0; e < NC; e++) launder<M>(c[e]);
+    // right -> left: x_i + E_i x_{i-1} = h_i - q_i xR
+    {
+        float r[NC], h0[NC], h1[NC], q[NC];
+#pragma unroll
+        for (int e = 0; e < NC; e++) {
+            const float ci = c[e][M - 2];
+            const float a = (M - 2 == 0) ? a_s[e] : c[e][(M - 3 > 0) ? M - 3 : 0];
+            r[e] = rcp_nr((1.0f - a) - ci);
+            h0[e] = f0[e][M - 2] * r[e]; h1[e] = (R > 1) ? f1[e][M - 2] * r[e] : 0.0f; q[e] = ci * r[e];
+        }
+#pragma unroll
+        for (int i = M - 3; i >= 0; i--) {
+#pragma unroll
+            for (int e = 0; e < NC; e++) {
+                const float ci = c[e][i];
+                const float a = (i == 0) ? a_s[e] : c[e][(i > 0) ? i - 1 : 0];
+                const float b = (1.0f - a) - ci;
+                r[e] = rcp_nr(__builtin_fmaf(-ci * ci, r[e], b));
+                h0[e] = __builtin_fmaf(-ci, h0[e], f0[e][i]) * r[e];
+                if (R > 1) h1[e] = __builtin_fmaf(-ci, h1[e], f1[e][i]) * r[e];
+                q[e] = (-ci * q[e]) * r[e];
+                asm volatile("" : "+v"(q[e]));
+            }
+            ADF_STEP_FENCE();
+        }
+#pragma unroll
+        for (int e = 0; e < NC; e++) { o[e].GS0 = h0[e]; o[e].GS1 = h1[e]; o[e].PS = a_s[e] * r[e]; o[e].QS = q[e]; }
+    }
+}
+
+// Phase 2: interior Thomas solve with both neighbours known; solutions overwrite f0 / f1.
+template <int M, int R, int NC>
+__device__ __forceinline__ void chunk_solve(float (&c)[NC][M], float (&f0)[NC][M], float (&f1)[NC][M],
+                                            const float (&a_s)[NC], const float (&xL0)[NC], const float (&xL1)[NC],
+                                            const float (&xR0)[NC], const float (&xR1)[NC])
+{
+#pragma unroll
+    for (int e = 0; e < NC; e++) launder<M>(c[e]);
+    float corig[NC], D[NC], g0[NC], g1[NC];
+#pragma unroll
+    for (int e = 0; e < NC; e++) {
+        const float a = a_s[e];
+        corig[e] = c[e][0];
+        const float r = rcp_nr((1.0f - a) - corig[e]);
+        D[e] = corig[e] * r;
+        g0[e] = __builtin_fmaf(-a, xL0[e], f0[e][0]) * r;
+        g1[e] = (R > 1) ? __builtin_fmaf(-a, xL1[e], f1[e][0]) * r : 0.0f;
+        c[e][0] = D[e]; f0[e][0] = g0[e]; if (R > 1) f1[e][0] = g1[e];
+    }
+#pragma unroll
+    for (int i = 1; i <= M - 2; i++) {
+#pragma unroll
+        for (int e = 0; e < NC; e++) {
+            const float a = corig[e];
+            corig[e] = c[e][i];
+            const float b = (1.0f - a) - corig[e];
+            const float r = rcp_nr(__builtin_fmaf(-a, D[e], b));
+            D[e] = corig[e] * r;
+            g0[e] = __builtin_fmaf(-a, g0[e], f0[e][i]) * r;
+            if (R > 1) g1[e] = __builtin_fmaf(-a, g1[e], f1[e][i]) * r;
+            c[e][i] = D[e]; f0[e][i] = g0[e]; if (R > 1) f1[e][i] = g1[e];
+        }
+        ADF_STEP_FENCE();
+    }
+    float x0[NC], x1[NC];
+#pragma unroll
+    for (int e = 0; e < NC; e++) {
+        x0[e] = xR0[e]; x1[e] = xR1[e];
+        f0[e][M - 1] = x0[e]; if (R > 1) f1[e][M - 1] = x1[e];
+    }
+#pragma unroll
+    for (int i = M - 2; i >= 0; i--) {
+#pragma unroll
+        for (int e = 0; e < NC; e++) {
+            x0[e] = __builtin_fmaf(-c[e][i], x0[e], f0[e][i]);
+            f0[e][i] = x0[e];
+            if (R > 1) { x1[e] = __builtin_fmaf(-c[e][i], x1[e], f1[e][i]); f1[e][i] = x1[e]; }
+        }
+        ADF_STEP_FENCE();
+    }
+}
+
+// Separator equation of a chunk: alpha*x_prev + beta*x + gamma*x_next = phi.
+// nGS*/nPS/nQS are the NEXT chunk's left-end coefficients (zero for the last chunk).
+template <int M, int R>
+__device__ __forceinline__ void separator_row(const float (&c)[M], const float (&f0)[M], const float (&f1)[M],
+                                              const Boundary<R>& o, float nGS0, float nGS1, float nPS, float nQS,
+                                              float& al, float& be, float& ga, float& p0, float& p1)
+{
+    const float ae = c[M - 2], ce = c[M - 1];
+    const float bb = (1.0f - ae) - ce;
+    al = -ae * o.PE;
+    be = __builtin_fmaf(-ce, nPS, __builtin_fmaf(-ae, o.QE, bb));
+    ga = -ce * nQS;
+    p0 = __builtin_fmaf(-ce, nGS0, __builtin_fmaf(-ae, o.GE0, f0[M - 1]));
+    p1 = (R > 1) ? __builtin_fmaf(-ce, nGS1, __builtin_fmaf(-ae, o.GE1, f1[M - 1])) : 0.0f;
+}
+
+// Parallel cyclic reduction of a 64-row tridiagonal system held one row per lane.
+template <int R>
+__device__ __forceinline__ void pcr64(int lane, float al, float be, float ga, float p0, float p1, float& x0, float& x1)
+{
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        float am = __shfl_up(al, d), bm = __shfl_up(be, d), gm = __shfl_up(ga, d), fm0 = __shfl_up(p0, d);
+        float fm1 = (R > 1) ? __shfl_up(p1, d) : 0.0f;
+        float ap = __shfl_down(al, d), bp = __shfl_down(be, d), gp = __shfl_down(ga, d), fp0 = __shfl_down(p0, d);
+        float fp1 = (R > 1) ? __shfl_down(p1, d) : 0.0f;
+        if (lane < d) { am = 0.0f; bm = 1.0f; gm = 0.0f; fm0 = 0.0f; fm1 = 0.0f; }
+        if (lane + d > 63) { ap = 0.0f; bp = 1.0f; gp = 0.0f; fp0 = 0.0f; fp1 = 0.0f; }
+        const float k1 = al * rcp_nr(bm), k2 = ga * rcp_nr(bp);
+        be = __builtin_fmaf(-ap, k2, __builtin_fmaf(-gm, k1, be));
+        p0 = __builtin_fmaf(-fp0, k2, __builtin_fmaf(-fm0, k1, p0));
+        if (R > 1) p1 = __builtin_fmaf(-fp1, k2, __builtin_fmaf(-fm1, k1, p1));
+        al = -am * k1;
+        ga = -gp * k2;
+    }
+    const float rb = rcp_nr(be);
+    x0 = p0 * rb;
+    x1 = (R > 1) ? p1 * rb : 0.0f;
+}
+
+
+} // namespace wave
+} // namespace adf

@@ -1,0 +1,110 @@
+// fgs_wave_h.hip -- horizontal pass of the on-chip partitioned solver (see fgs_wave_common.h).
+#include "fgs_wave_common.h"
+
+namespace adf {
+
+namespace {
+using namespace wave;
+
+// ---------------------------------------------------------------------------------------------
+// Horizontal pass: one wavefront per row, in place.
+// ---------------------------------------------------------------------------------------------
+template <int M, int R>
+__global__ void __launch_bounds__(64, 2) wave_hpass_kernel(WavePassArgs a)
+{
+    static_assert(M % 4 == 0 && M >= 4, "chunk length must be a multiple of 4");
+    __shared__ float4 stage[M * 16];
+    const int lane = threadIdx.x;
+    const size_t off = (size_t)blockIdx.y * a.plane + (size_t)blockIdx.x * a.pitch;
+    const int nvec = a.pitch >> 2;
+    float c[1][M], f0[1][M], f1[1][M];
+
+    auto load_row = [&](const float* src, float (&dst)[M], float scale) {
+        const float4* s4 = reinterpret_cast<const float4*>(src + off);
+#pragma unroll
+        for (int k = 0; k < M / 4; k++) {
+            const int idx = 64 * k + lane;
+            stage[idx] = idx < nvec ? s4[idx] : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < M / 4; k++) {
+            // columns [len, pitch) of every plane are zero by construction (the host zeroes the
+            // workspace whenever the geometry changes and no kernel writes non-zeros there), and
+            // float4s past the pitch were staged as zeros: the tail is identity rows without masks
+            const float4 v = stage[lane * (M / 4) + k];
+            dst[4 * k + 0] = v.x * scale;
+            dst[4 * k + 1] = v.y * scale;
+            dst[4 * k + 2] = v.z * scale;
+            dst[4 * k + 3] = v.w * scale;
+        }
+        __syncthreads();
+    };
+    load_row(a.C, c[0], a.lambda);
+    load_row(a.U0, f0[0], 1.0f);
+    if (R > 1) load_row(a.U1, f1[0], 1.0f);
+    else {
+#pragma unroll
+        for (int i = 0; i < M; i++) f1[0][i] = 0.0f;
+    }
+
+    float a_s[1] = {__shfl_up(c[0][M - 1], 1)};
+    if (lane == 0) a_s[0] = 0.0f;
+
+    Boundary<R> bd[1];
+    chunk_boundary<M, R, 1>(c, f0, f1, a_s, bd);
+    float nGS0 = __shfl_down(bd[0].GS0, 1), nGS1 = (R > 1) ? __shfl_down(bd[0].GS1, 1) : 0.0f;
+    float nPS = __shfl_down(bd[0].PS, 1), nQS = __shfl_down(bd[0].QS, 1);
+    if (lane == 63) { nGS0 = 0.0f; nGS1 = 0.0f; nPS = 0.0f; nQS = 0.0f; }
+    float al, be, ga, p0, p1, xs0[1], xs1[1];
+    separator_row<M, R>(c[0], f0[0], f1[0], bd[0], nGS0, nGS1, nPS, nQS, al, be, ga, p0, p1);
+    pcr64<R>(lane, al, be, ga, p0, p1, xs0[0], xs1[0]);
+    float xL0[1] = {__shfl_up(xs0[0], 1)}, xL1[1] = {(R > 1) ? __shfl_up(xs1[0], 1) : 0.0f};
+    if (lane == 0) { xL0[0] = 0.0f; xL1[0] = 0.0f; }
+    chunk_solve<M, R, 1>(c, f0, f1, a_s, xL0, xL1, xs0, xs1);
+
+    auto store_row = [&](float* dstp, const float (&src)[M]) {
+#pragma unroll
+        for (int k = 0; k < M / 4; k++)
+            stage[lane * (M / 4) + k] = make_float4(src[4 * k], src[4 * k + 1], src[4 * k + 2], src[4 * k + 3]);
+        __syncthreads();
+        float4* d4 = reinterpret_cast<float4*>(dstp + off);
+#pragma unroll
+        for (int k = 0; k < M / 4; k++) {
+            const int idx = 64 * k + lane;
+            if (idx < nvec) d4[idx] = stage[idx];
+        }
+        __syncthreads();
+    };
+    store_row(a.U0, f0[0]);
+    if (R > 1) store_row(a.U1, f1[0]);
+}
+
+template <int M>
+hipError_t launch_h(const WavePassArgs& a, int n_rhs, int n_pairs, hipStream_t st)
+{
+    dim3 grid(a.nscan, n_pairs), block(64);
+    if (n_rhs == 2) hipLaunchKernelGGL((wave_hpass_kernel<M, 2>), grid, block, 0, st, a);
+    else hipLaunchKernelGGL((wave_hpass_kernel<M, 1>), grid, block, 0, st, a);
+    return hipGetLastError();
+}
+
+} // namespace
+
+int wave_max_row_len() { return 64 * 64; }
+
+hipError_t launch_wave_hpass(const WavePassArgs& a, int n_rhs, int n_pairs, hipStream_t st)
+{
+    if (a.len < 2 || a.len > wave_max_row_len() || a.pitch % 64 != 0 || a.pitch < a.len) return hipErrorInvalidValue;
+    const int m = (a.len + 63) / 64;
+    if (m <= 4) return launch_h<4>(a, n_rhs, n_pairs, st);
+    if (m <= 8) return launch_h<8>(a, n_rhs, n_pairs, st);
+    if (m <= 16) return launch_h<16>(a, n_rhs, n_pairs, st);
+    if (m <= 20) return launch_h<20>(a, n_rhs, n_pairs, st);
+    if (m <= 28) return launch_h<28>(a, n_rhs, n_pairs, st);
+    if (m <= 40) return launch_h<40>(a, n_rhs, n_pairs, st);
+    if (m <= 56) return launch_h<56>(a, n_rhs, n_pairs, st);
+    return launch_h<64>(a, n_rhs, n_pairs, st);
+}
+
+} // namespace adf

@@ -1,0 +1,184 @@
+// fgs_wave_v.hip -- vertical pass of the on-chip partitioned solver (see fgs_wave_common.h).
+// Built with -fno-slp-vectorize: the SLP vectorizer packs the per-element temporaries of the unrolled
+// sweeps into v_pk_* bundles hoisted to the front of the sweep, which costs ~50 registers at the
+// chunk length a 2160-row column needs and turns into scratch spills.
+#include "fgs_wave_common.h"
+
+namespace adf {
+
+namespace {
+using namespace wave;
+
+// ---------------------------------------------------------------------------------------------
+// Vertical pass: one 512-thread workgroup per 16-column strip, in place (or fused epilogue).
+// thread = (chunk cidx in [0,64), column pair xp in [0,8)); M rows x 2 columns per thread.
+// ---------------------------------------------------------------------------------------------
+constexpr int VT = 512;  // threads per strip
+constexpr int VC = 16;   // columns per strip
+
+template <int M, int R, int EPI>
+__global__ void __launch_bounds__(VT) wave_vpass_kernel(WavePassArgs a)
+{
+    __shared__ float nb[4][64][VC];   // next-chunk exchange: GS0, GS1, PS, QS
+    __shared__ float red[5][VC][64];  // separator rows by (column, chunk)
+    __shared__ float xs[2][VC][64];   // separator solutions
+    const int tid = threadIdx.x;
+    const int xp = tid & 7, cidx = tid >> 3;
+    const int col = blockIdx.x * VC + 2 * xp;       // < pitch by construction of the grid
+    const size_t pb = (size_t)blockIdx.y * a.plane;
+    const int r0 = cidx * M;
+    const int h = a.len;                            // scanline length = ROI height
+
+    // Addressing: wave-uniform plane bases (SGPRs) + one 32-bit byte offset per thread that walks down
+    // the rows.  Keeping a 64-bit address per row alive from the loads to the stores would cost more
+    // registers than the strip itself.
+    const char* bC = reinterpret_cast<const char*>(a.C + pb);
+    char* b0 = reinterpret_cast<char*>(a.U0 + pb);
+    char* b1 = (R > 1) ? reinterpret_cast<char*>(a.U1 + pb) : nullptr;
+    const unsigned pitch_b = (unsigned)a.pitch * 4u;
+    const unsigned voff0 = ((unsigned)r0 * (unsigned)a.pitch + (unsigned)col) * 4u;
+
+    float c[2][M], f0[2][M], f1[2][M];
+    {
+        unsigned voff = voff0;
+#pragma unroll
+        for (int i = 0; i < M; i++) {
+            // rows past the end of the column are identity rows (c = 0, f = 0); their loads are
+            // redirected to the chunk's first row so that no load sits under a divergent branch
+            const bool ok = r0 + i < h;
+            const unsigned vo = ok ? voff : voff0;
+            const float2 vc = *reinterpret_cast<const float2*>(bC + vo);
+            const float2 v0 = *reinterpret_cast<const float2*>(b0 + vo);
+            float2 v1 = make_float2(0.f, 0.f);
+            if (R > 1) v1 = *reinterpret_cast<const float2*>(b1 + vo);
+            c[0][i] = ok ? vc.x * a.lambda : 0.0f; c[1][i] = ok ? vc.y * a.lambda : 0.0f;
+            f0[0][i] = ok ? v0.x : 0.0f; f0[1][i] = ok ? v0.y : 0.0f;
+            f1[0][i] = ok ? v1.x : 0.0f; f1[1][i] = ok ? v1.y : 0.0f;
+            voff += pitch_b;
+        }
+    }
+    float a_s[2] = {0.0f, 0.0f};
+    if (cidx > 0 && r0 - 1 < h) {
+        const float2 v = *reinterpret_cast<const float2*>(bC + (voff0 - pitch_b));
+        a_s[0] = v.x * a.lambda; a_s[1] = v.y * a.lambda;
+    }
+
+    Boundary<R> bd[2];
+    chunk_boundary<M, R, 2>(c, f0, f1, a_s, bd);
+#pragma unroll
+    for (int e = 0; e < 2; e++) {
+        nb[0][cidx][2 * xp + e] = bd[e].GS0;
+        nb[1][cidx][2 * xp + e] = bd[e].GS1;
+        nb[2][cidx][2 * xp + e] = bd[e].PS;
+        nb[3][cidx][2 * xp + e] = bd[e].QS;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int e = 0; e < 2; e++) {
+        float nGS0 = 0.f, nGS1 = 0.f, nPS = 0.f, nQS = 0.f;
+        if (cidx < 63) {
+            nGS0 = nb[0][cidx + 1][2 * xp + e]; nGS1 = nb[1][cidx + 1][2 * xp + e];
+            nPS = nb[2][cidx + 1][2 * xp + e]; nQS = nb[3][cidx + 1][2 * xp + e];
+        }
+        float al, be, ga, p0, p1;
+        separator_row<M, R>(c[e], f0[e], f1[e], bd[e], nGS0, nGS1, nPS, nQS, al, be, ga, p0, p1);
+        red[0][2 * xp + e][cidx] = al; red[1][2 * xp + e][cidx] = be; red[2][2 * xp + e][cidx] = ga;
+        red[3][2 * xp + e][cidx] = p0; red[4][2 * xp + e][cidx] = p1;
+    }
+    __syncthreads();
+    {   // 8 wavefronts x 2 columns each: one separator row per lane
+        const int wv = tid >> 6, lane = tid & 63;
+#pragma unroll
+        for (int e = 0; e < 2; e++) {
+            const int cc = 2 * wv + e;
+            float x0, x1;
+            pcr64<R>(lane, red[0][cc][lane], red[1][cc][lane], red[2][cc][lane], red[3][cc][lane], red[4][cc][lane], x0, x1);
+            xs[0][cc][lane] = x0; xs[1][cc][lane] = x1;
+        }
+    }
+    __syncthreads();
+    {
+        float xL0[2], xL1[2], xR0[2], xR1[2];
+#pragma unroll
+        for (int e = 0; e < 2; e++) {
+            const int cc = 2 * xp + e;
+            xR0[e] = xs[0][cc][cidx]; xR1[e] = xs[1][cc][cidx];
+            xL0[e] = cidx > 0 ? xs[0][cc][cidx - 1] : 0.0f; xL1[e] = cidx > 0 ? xs[1][cc][cidx - 1] : 0.0f;
+        }
+        chunk_solve<M, R, 2>(c, f0, f1, a_s, xL0, xL1, xR0, xR1);
+    }
+
+    unsigned voff = voff0;
+    asm volatile("" : "+v"(voff)); // recompute the row offsets instead of keeping the load addresses alive
+    if (EPI == EPI_PLANES) {
+#pragma unroll
+        for (int i = 0; i < M; i++) {
+            if (r0 + i < h) {
+                *reinterpret_cast<float2*>(b0 + voff) = make_float2(f0[0][i], f0[1][i]);
+                if (R > 1) *reinterpret_cast<float2*>(b1 + voff) = make_float2(f1[0][i], f1[1][i]);
+            }
+            voff += pitch_b;
+        }
+    } else {
+        char* ob = reinterpret_cast<char*>(a.out) + (ptrdiff_t)blockIdx.y * a.out_pair_stride +
+                   (ptrdiff_t)(a.out_y0 + r0) * a.out_stride;
+        const int esz = (EPI == EPI_F32) ? 4 : (EPI == EPI_U8) ? 1 : 2;
+        unsigned ooff = (unsigned)((a.out_x0 + col) * a.out_cn + a.out_c) * (unsigned)esz;
+#pragma unroll
+        for (int i = 0; i < M; i++) {
+            if (r0 + i < h) {
+#pragma unroll
+                for (int e = 0; e < 2; e++) {
+                    if (col + e < a.nscan) {
+                        char* dst = ob + ooff + (unsigned)(e * a.out_cn * esz);
+                        if (EPI == EPI_WLS_CONF) {
+                            const float rcp = 1.0f / (f1[e][i] + ADF_EPS);                 // DF.cpp:295
+                            *reinterpret_cast<int16_t*>(dst) = sat16(f0[e][i] * rcp);      // DF.cpp:296
+                        } else if (EPI == EPI_I16)
+                            *reinterpret_cast<int16_t*>(dst) = sat16(f0[e][i]);
+                        else if (EPI == EPI_U8)
+                            *reinterpret_cast<uint8_t*>(dst) = sat8(f0[e][i]);
+                        else
+                            *reinterpret_cast<float*>(dst) = f0[e][i];
+                    }
+                }
+            }
+            ooff += (unsigned)a.out_stride;
+        }
+    }
+}
+
+template <int M>
+hipError_t launch_v(const WavePassArgs& a, int n_rhs, int epi, int n_pairs, hipStream_t st)
+{
+    dim3 grid(a.pitch / VC, n_pairs), block(VT);
+#define ADF_LV(RR, EE) hipLaunchKernelGGL((wave_vpass_kernel<M, RR, EE>), grid, block, 0, st, a)
+    if (n_rhs == 2 && epi == EPI_PLANES) ADF_LV(2, EPI_PLANES);
+    else if (n_rhs == 2 && epi == EPI_WLS_CONF) ADF_LV(2, EPI_WLS_CONF);
+    else if (n_rhs == 1 && epi == EPI_PLANES) ADF_LV(1, EPI_PLANES);
+    else if (n_rhs == 1 && epi == EPI_I16) ADF_LV(1, EPI_I16);
+    else if (n_rhs == 1 && epi == EPI_F32) ADF_LV(1, EPI_F32);
+    else if (n_rhs == 1 && epi == EPI_U8) ADF_LV(1, EPI_U8);
+    else return hipErrorInvalidValue;
+#undef ADF_LV
+    return hipGetLastError();
+}
+
+} // namespace
+
+int wave_max_col_len() { return 64 * 34; }
+
+hipError_t launch_wave_vpass(const WavePassArgs& a, int n_rhs, int epilogue, int n_pairs, hipStream_t st)
+{
+    if (a.len < 2 || a.len > wave_max_col_len() || a.pitch % 64 != 0 || a.pitch < a.nscan) return hipErrorInvalidValue;
+    const int m = (a.len + 63) / 64;
+    if (m <= 2) return launch_v<2>(a, n_rhs, epilogue, n_pairs, st);
+    if (m <= 4) return launch_v<4>(a, n_rhs, epilogue, n_pairs, st);
+    if (m <= 8) return launch_v<8>(a, n_rhs, epilogue, n_pairs, st);
+    if (m <= 12) return launch_v<12>(a, n_rhs, epilogue, n_pairs, st);
+    if (m <= 18) return launch_v<18>(a, n_rhs, epilogue, n_pairs, st);
+    if (m <= 26) return launch_v<26>(a, n_rhs, epilogue, n_pairs, st);
+    return launch_v<34>(a, n_rhs, epilogue, n_pairs, st);
+}
+
+} // namespace adf

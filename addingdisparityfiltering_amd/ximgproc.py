@@ -177,6 +177,9 @@ class DisparityWLSFilter(DisparityFilter):
     def getSolver(self):
         return self._geti(_lib.lib().adf_wls_get_solver)
 
+    def getLastSolver(self):
+        return self._geti(_lib.lib().adf_wls_get_last_solver)
+
     def enableProfiling(self, on=True):
         """Bracket every kernel launch with HIP events on the caller's stream (measurement hook)."""
         _lib.check(_lib.lib().adf_wls_profile_enable(self._h, int(bool(on))))

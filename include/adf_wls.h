@@ -95,6 +95,9 @@ int adf_wls_get_depth_discontinuity_radius(const adf_wls_t* h, int* radius);
 int adf_wls_set_fgs_params(adf_wls_t* h, double lambda_attenuation, int num_iter);
 int adf_wls_set_solver(adf_wls_t* h, int solver);
 int adf_wls_get_solver(const adf_wls_t* h, int* solver);
+/* Solver the last filter call actually ran: ADF_SOLVER_WAVE covers ROIs up to 4096 x 2176; larger
+ * ones fall back to ADF_SOLVER_EXACT. */
+int adf_wls_get_last_solver(const adf_wls_t* h, int* solver);
 
 /* DisparityFilter::filter (DF.hpp:75, DF.cpp:219-298) on a batch of n_pairs
  * independent, equally sized stereo pairs laid out `*_pair_stride` bytes apart
