@@ -431,8 +431,9 @@ extern "C" int adf_wls_filter_device(adf_wls_t* h, int n_pairs,
 
         const double F = (double)g.frame * n, P = (double)g.rw * g.rh * n;
         Profiler* prof = &h->prof;
-        FillArgs fa{o, sO, psO, g, (int16_t)(16 * (h->min_disp - 1))};    // DF.cpp:254,284
-        {
+        const int16_t fill = (int16_t)(16 * (h->min_disp - 1));            // DF.cpp:254,284
+        if (!conf) {                                                       // with confidence the LRC kernel fills
+            FillArgs fa{o, sO, psO, g, fill};
             ProfScope ps(prof, K_FILL, 2.0 * (F - P), 2.0 * (F - P), st);
             HIP_TRY(launch_fill_outside(fa, n, st));
         }
@@ -445,22 +446,19 @@ extern "C" int adf_wls_filter_device(adf_wls_t* h, int n_pairs,
         if (conf) {
             const int16_t* dRp = (const int16_t*)((const char*)dispR + (ptrdiff_t)first * psR);
             const int rrx = W - (roi.x + roi.width);                       // DF.cpp:202
-            DiscArgs da{dL, sL, psL, roi.x, roi.y, roi.width, roi.height, h->disc_radius, h->roll_off,
-                        cL, W, g.frame};
-            {   // reads the int16 ROI, writes the float map (the maps themselves are not algorithmic I/O)
-                ProfScope ps(prof, K_DISC, 2.0 * P, 6.0 * P, st);
+            DiscArgs da{};
+            da.disp[0] = dL; da.stride[0] = sL; da.pair_stride[0] = psL; da.rx[0] = roi.x; da.dst[0] = cL;
+            da.disp[1] = dRp; da.stride[1] = sR; da.pair_stride[1] = psR; da.rx[1] = rrx; da.dst[1] = cR;
+            da.ry = roi.y; da.rw = roi.width; da.rh = roi.height; da.radius = h->disc_radius;
+            da.roll_off = h->roll_off; da.W = W; da.frame = g.frame;
+            {   // reads the int16 ROIs, writes the float maps (the maps themselves are not algorithmic I/O)
+                ProfScope ps(prof, K_DISC, 4.0 * P, 12.0 * P, st);
                 HIP_TRY(launch_discontinuity(da, n, st));                  // DF.cpp:204
             }
-            DiscArgs db{dRp, sR, psR, rrx, roi.y, roi.width, roi.height, h->disc_radius, h->roll_off,
-                        cR, W, g.frame};
-            {
-                ProfScope ps(prof, K_DISC, 2.0 * P, 6.0 * P, st);
-                HIP_TRY(launch_discontinuity(db, n, st));
-            }
             LrcArgs la{dL, sL, psL, dRp, sR, psR, cL, cR, (float*)h->conf.p + (size_t)first * g.frame,
-                       p.A0, p.A1, g, rrx, (int)(1.0f * h->lrc_thresh) /* DF.cpp:318 */, orient_h};
+                       o, sO, psO, fill, p.A0, p.A1, g, rrx, (int)(1.0f * h->lrc_thresh) /* DF.cpp:318 */, orient_h};
             {   // alg: confidence map out (4F) + the two rhs planes (8P); moved adds dL,dR,cL,cR reads
-                ProfScope ps(prof, K_LRC, 4.0 * F + 8.0 * P, 4.0 * F + 20.0 * P, st);
+                ProfScope ps(prof, K_LRC, 4.0 * F + 8.0 * P + 2.0 * (F - P), 4.0 * F + 20.0 * P + 2.0 * (F - P), st);
                 HIP_TRY(launch_lrc_prologue(la, n, st));                   // DF.cpp:208-209,288-290
             }
             FinalOut fo{EPI_WLS_CONF, o, sO, psO, roi.x, roi.y, 1, 0};

@@ -35,11 +35,12 @@ enum Epilogue {
     EPI_U8 = 4        // uint8 = sat(u0)                  FGS.cpp:216
 };
 
+// Both views of a pair in one launch: index 0 = left, 1 = right (mirrored ROI x, DF.cpp:202-203).
 struct DiscArgs {
-    const int16_t* disp; ptrdiff_t stride, pair_stride; // bytes
-    int rx, ry, rw, rh;  // ROI of THIS view
+    const int16_t* disp[2]; ptrdiff_t stride[2], pair_stride[2]; // bytes
+    int rx[2]; int ry, rw, rh;
     int radius; float roll_off;
-    float* dst; int W; size_t frame; // full-frame float plane, W pitch
+    float* dst[2]; int W; size_t frame; // full-frame float planes, W pitch
 };
 
 struct LrcArgs {
@@ -47,6 +48,7 @@ struct LrcArgs {
     const int16_t* dR; ptrdiff_t sR, psR;
     const float* cL; const float* cR; // full-frame discontinuity maps
     float* conf;                      // full-frame confidence (x255), zero outside ROI
+    int16_t* out; ptrdiff_t sO, psO; int16_t fill; // filtered map: `fill` outside the ROI (DF.cpp:284); may be null
     float* U0; float* U1;             // ROI planes: conf*disp, conf
     Geom g; int rrx;                  // right ROI x (DF.cpp:202)
     int thresh; int orient;           // orientation of U0/U1

@@ -26,66 +26,74 @@ constexpr int NT = 256;
 constexpr int MAX_RADIUS = 40;
 
 // ---------------------------------------------------------------------------------------
-// Depth-discontinuity map of one view.  One block = one TX x TY tile of ROI outputs.
-// LDS: int16 input tile with halo, then horizontal window sums (int32 sum, int64 sum of
-// squares; both exact), then vertical window sums by sliding windows of 8 outputs.
+// Depth-discontinuity maps.  One block = one TX x TY tile of ROI outputs of one view of one pair
+// (blockIdx.z = 2*pair + view).  LDS: int16 input tile with halo, then horizontal window sums
+// (int32 sum, int64 sum of squares; both exact), then vertical window sums, both by sliding
+// windows of 8 outputs.  No integer division anywhere: all index maps are 2-D loops.
 // ---------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(NT) discontinuity_kernel(DiscArgs a)
 {
     extern __shared__ __align__(16) unsigned char smem[];
     const int r = a.radius, k = 2 * r + 1;
     const int IH = TY + 2 * r, IW = TX + 2 * r;
+    const int IWP = IW | 1;                                              // odd pitch (in int16)
     long long* h2 = reinterpret_cast<long long*>(smem);                  // [IH][TX]
     int* h1 = reinterpret_cast<int*>(h2 + (size_t)IH * TX);              // [IH][TX]
-    int16_t* in = reinterpret_cast<int16_t*>(h1 + (size_t)IH * TX);      // [IH][IW]
+    int16_t* in = reinterpret_cast<int16_t*>(h1 + (size_t)IH * TX);      // [IH][IWP]
 
-    const int tid = threadIdx.x;
+    const int tid = threadIdx.x, tx = tid & (TX - 1), ty = tid / TX;
     const int x0 = blockIdx.x * TX, y0 = blockIdx.y * TY;
-    const char* base = reinterpret_cast<const char*>(a.disp) + (ptrdiff_t)blockIdx.z * a.pair_stride;
+    const int view = blockIdx.z & 1;
+    const size_t pz = blockIdx.z >> 1;
+    const char* base = reinterpret_cast<const char*>(a.disp[view]) + (ptrdiff_t)pz * a.pair_stride[view];
+    const int rx = a.rx[view];
 
-    for (int idx = tid; idx < IH * IW; idx += NT) {
-        int yy = idx / IW, xx = idx - yy * IW;
-        int gy = reflect101(y0 + yy - r, a.rh);
-        int gx = reflect101(x0 + xx - r, a.rw);
-        const int16_t* row = reinterpret_cast<const int16_t*>(base + (ptrdiff_t)(a.ry + gy) * a.stride);
-        in[idx] = row[a.rx + gx];
+    for (int yy = ty; yy < IH; yy += NT / TX) {
+        const int gy = reflect101(y0 + yy - r, a.rh);
+        const int16_t* row = reinterpret_cast<const int16_t*>(base + (ptrdiff_t)(a.ry + gy) * a.stride[view]) + rx;
+        for (int xx = tx; xx < IW; xx += TX)
+            in[yy * IWP + xx] = row[reflect101(x0 + xx - r, a.rw)];
     }
     __syncthreads();
 
-    // horizontal sums: work item = (row, segment of 8 outputs)
-    for (int item = tid; item < IH * (TX / 8); item += NT) {
-        int yy = item / (TX / 8), xs = (item - yy * (TX / 8)) * 8;
-        const int16_t* p = in + yy * IW + xs;
+    // horizontal sums: work item = (row, segment of 8 outputs); 8 segments per row
+    for (int item = tid; item < IH * 8; item += NT) {
+        const int yy = item >> 3, xs = (item & 7) * 8;
+        const int16_t* p = in + yy * IWP + xs;
         int s1 = 0; long long s2 = 0;
-        for (int q = 0; q < k; q++) { int v = p[q]; s1 += v; s2 += (long long)(v * v); }
-        h1[yy * TX + xs] = s1; h2[yy * TX + xs] = s2;
+        for (int q = 0; q < k; q++) { const int v = p[q]; s1 += v; s2 += (long long)(v * v); }
+        int* o1 = h1 + yy * TX + xs; long long* o2 = h2 + yy * TX + xs;
+        o1[0] = s1; o2[0] = s2;
+#pragma unroll
         for (int i = 1; i < 8; i++) {
-            int va = p[i + k - 1], vb = p[i - 1];
-            s1 += va - vb; s2 += (long long)(va * va) - (long long)(vb * vb);
-            h1[yy * TX + xs + i] = s1; h2[yy * TX + xs + i] = s2;
+            const int va = p[i + k - 1], vb = p[i - 1];
+            s1 += va - vb; s2 += (long long)(va * va - vb * vb);
+            o1[i] = s1; o2[i] = s2;
         }
     }
     __syncthreads();
 
     // vertical sums: thread = (column, segment of 8 rows)
     {
-        const int x = tid % TX, ys = (tid / TX) * 8;
+        const int ys = ty * 8;
         const double scale = 1.0 / ((double)k * (double)k);
         int s1 = 0; long long s2 = 0;
-        for (int q = 0; q < k; q++) { s1 += h1[(ys + q) * TX + x]; s2 += h2[(ys + q) * TX + x]; }
-        float* dst = a.dst + (size_t)blockIdx.z * a.frame;
+        for (int q = 0; q < k; q++) { s1 += h1[(ys + q) * TX + tx]; s2 += h2[(ys + q) * TX + tx]; }
+        float* dst = a.dst[view] + pz * a.frame;
+        const int gx = x0 + tx;
+#pragma unroll
         for (int i = 0; i < 8; i++) {
             if (i > 0) {
-                s1 += h1[(ys + i + k - 1) * TX + x] - h1[(ys + i - 1) * TX + x];
-                s2 += h2[(ys + i + k - 1) * TX + x] - h2[(ys + i - 1) * TX + x];
+                s1 += h1[(ys + i + k - 1) * TX + tx] - h1[(ys + i - 1) * TX + tx];
+                s2 += h2[(ys + i + k - 1) * TX + tx] - h2[(ys + i - 1) * TX + tx];
             }
-            int gy = y0 + ys + i, gx = x0 + x;
+            const int gy = y0 + ys + i;
             if (gy < a.rh && gx < a.rw) {
-                float mean = (float)((double)s1 * scale);
-                float sq = (float)((double)s2 * scale);
-                float variance = sq - mean * mean;       // DF.cpp:369
-                float v = 1.0f - a.roll_off * variance;  // DF.cpp:370
-                dst[(size_t)(a.ry + gy) * a.W + a.rx + gx] = v < 0.0f ? 0.0f : v;
+                const float mean = (float)((double)s1 * scale);
+                const float sq = (float)((double)s2 * scale);
+                const float variance = sq - mean * mean;       // DF.cpp:369
+                const float v = 1.0f - a.roll_off * variance;  // DF.cpp:370
+                dst[(size_t)(a.ry + gy) * a.W + rx + gx] = v < 0.0f ? 0.0f : v;
             }
         }
     }
@@ -136,7 +144,12 @@ __global__ void __launch_bounds__(NT) lrc_prologue_kernel(LrcArgs a)
             c = 255.0f * c;                                             // DF.cpp:209
             u0 = c * (float)d;                                          // DF.cpp:289-290
         }
-        if (in_frame) conf[(size_t)i * g.W + j] = c;
+        if (in_frame) {
+            conf[(size_t)i * g.W + j] = c;
+            if (a.out && !in_roi)                                          // DF.cpp:284
+                reinterpret_cast<int16_t*>(reinterpret_cast<char*>(a.out) + (ptrdiff_t)pz * a.psO +
+                                           (ptrdiff_t)i * a.sO)[j] = a.fill;
+        }
         if (a.orient == ORIENT_N) {
             if (in_roi) {
                 size_t o = (size_t)(i - g.ry) * g.pw + (j - g.rx);
@@ -214,8 +227,8 @@ __global__ void __launch_bounds__(NT) fill_outside_kernel(FillArgs a)
 
 inline size_t disc_lds_bytes(int r)
 {
-    const size_t IH = TY + 2 * r, IW = TX + 2 * r;
-    return IH * TX * 8 + IH * TX * 4 + ((IH * IW * 2 + 15) & ~(size_t)15);
+    const size_t IH = TY + 2 * r, IWP = (TX + 2 * r) | 1;
+    return IH * TX * 8 + IH * TX * 4 + ((IH * IWP * 2 + 15) & ~(size_t)15);
 }
 
 } // namespace
@@ -225,6 +238,7 @@ int max_disc_radius() { return MAX_RADIUS; }
 hipError_t launch_discontinuity(const DiscArgs& a, int n_pairs, hipStream_t st)
 {
     if (a.rw <= 0 || a.rh <= 0 || n_pairs <= 0) return hipSuccess;
+    static_assert(TX == 64 && TY == 32 && NT == 256, "discontinuity_kernel assumes a 64x32 tile and 256 threads");
     if (a.radius < 0 || a.radius > MAX_RADIUS) return hipErrorInvalidValue;
     const size_t lds = disc_lds_bytes(a.radius);
     static size_t configured = 0;
@@ -234,7 +248,7 @@ hipError_t launch_discontinuity(const DiscArgs& a, int n_pairs, hipStream_t st)
         if (e != hipSuccess) return e;
         configured = lds;
     }
-    dim3 grid((a.rw + TX - 1) / TX, (a.rh + TY - 1) / TY, n_pairs);
+    dim3 grid((a.rw + TX - 1) / TX, (a.rh + TY - 1) / TY, 2 * n_pairs);
     hipLaunchKernelGGL(discontinuity_kernel, grid, dim3(NT), lds, st, a);
     return hipGetLastError();
 }

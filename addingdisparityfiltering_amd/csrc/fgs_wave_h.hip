@@ -19,34 +19,49 @@ __global__ void __launch_bounds__(64, 2) wave_hpass_kernel(WavePassArgs a)
     const int nvec = a.pitch >> 2;
     float c[1][M], f0[1][M], f1[1][M];
 
-    auto load_row = [&](const float* src, float (&dst)[M], float scale) {
-        const float4* s4 = reinterpret_cast<const float4*>(src + off);
+    // All of the row's coalesced loads (16 B per lane, 1 KiB per instruction) are issued before the
+    // first use so that a row pays one memory latency, not one per plane; each plane is then turned
+    // from "float4 #(64k+lane)" into "chunk of lane" through the wave's LDS staging buffer.
+    float4 tC[M / 4], t0[M / 4], t1[M / 4];
+    {
+        const float4* sC = reinterpret_cast<const float4*>(a.C + off);
+        const float4* s0 = reinterpret_cast<const float4*>(a.U0 + off);
+        const float4* s1 = (R > 1) ? reinterpret_cast<const float4*>(a.U1 + off) : nullptr;
+        // (an explicit branch per load: "cond ? *p : zero" would make the compiler select between
+        // addresses and park the zero in scratch memory)
 #pragma unroll
         for (int k = 0; k < M / 4; k++) {
             const int idx = 64 * k + lane;
-            stage[idx] = idx < nvec ? s4[idx] : make_float4(0.f, 0.f, 0.f, 0.f);
+            tC[k] = make_float4(0.f, 0.f, 0.f, 0.f); t0[k] = tC[k]; t1[k] = tC[k];
+            if (idx < nvec) {
+                tC[k] = sC[idx];
+                t0[k] = s0[idx];
+                if (R > 1) t1[k] = s1[idx];
+            }
         }
-        __syncthreads();
-#pragma unroll
-        for (int k = 0; k < M / 4; k++) {
-            // columns [len, pitch) of every plane are zero by construction (the host zeroes the
-            // workspace whenever the geometry changes and no kernel writes non-zeros there), and
-            // float4s past the pitch were staged as zeros: the tail is identity rows without masks
-            const float4 v = stage[lane * (M / 4) + k];
-            dst[4 * k + 0] = v.x * scale;
-            dst[4 * k + 1] = v.y * scale;
-            dst[4 * k + 2] = v.z * scale;
-            dst[4 * k + 3] = v.w * scale;
-        }
-        __syncthreads();
-    };
-    load_row(a.C, c[0], a.lambda);
-    load_row(a.U0, f0[0], 1.0f);
-    if (R > 1) load_row(a.U1, f1[0], 1.0f);
+    }
+    // columns [len, pitch) of every plane are zero by construction (the host zeroes the workspace
+    // whenever the geometry changes and no kernel writes non-zeros there), and float4s past the pitch
+    // were loaded as zeros: the tail of the row is identity rows without masks
+#define ADF_TRANSPOSE_IN(T, DST, SCALE)                                                   \
+    {                                                                                     \
+        _Pragma("unroll") for (int k = 0; k < M / 4; k++) stage[64 * k + lane] = T[k];    \
+        __syncthreads();                                                                  \
+        _Pragma("unroll") for (int k = 0; k < M / 4; k++) {                               \
+            const float4 v = stage[lane * (M / 4) + k];                                   \
+            DST[4 * k + 0] = v.x * (SCALE); DST[4 * k + 1] = v.y * (SCALE);               \
+            DST[4 * k + 2] = v.z * (SCALE); DST[4 * k + 3] = v.w * (SCALE);               \
+        }                                                                                 \
+        __syncthreads();                                                                  \
+    }
+    ADF_TRANSPOSE_IN(tC, c[0], a.lambda)
+    ADF_TRANSPOSE_IN(t0, f0[0], 1.0f)
+    if (R > 1) ADF_TRANSPOSE_IN(t1, f1[0], 1.0f)
     else {
 #pragma unroll
         for (int i = 0; i < M; i++) f1[0][i] = 0.0f;
     }
+#undef ADF_TRANSPOSE_IN
 
     float a_s[1] = {__shfl_up(c[0][M - 1], 1)};
     if (lane == 0) a_s[0] = 0.0f;

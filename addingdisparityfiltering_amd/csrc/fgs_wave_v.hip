@@ -127,19 +127,36 @@ __global__ void __launch_bounds__(VT) wave_vpass_kernel(WavePassArgs a)
 #pragma unroll
         for (int i = 0; i < M; i++) {
             if (r0 + i < h) {
+                if ((EPI == EPI_WLS_CONF || EPI == EPI_I16) && a.out_cn == 1 && col + 1 < a.nscan) {
+                    // both columns of the pair in one 4-byte store (rows are 2-byte aligned only)
+                    int16_t v[2];
 #pragma unroll
-                for (int e = 0; e < 2; e++) {
-                    if (col + e < a.nscan) {
-                        char* dst = ob + ooff + (unsigned)(e * a.out_cn * esz);
+                    for (int e = 0; e < 2; e++) {
                         if (EPI == EPI_WLS_CONF) {
                             const float rcp = 1.0f / (f1[e][i] + ADF_EPS);                 // DF.cpp:295
-                            *reinterpret_cast<int16_t*>(dst) = sat16(f0[e][i] * rcp);      // DF.cpp:296
-                        } else if (EPI == EPI_I16)
-                            *reinterpret_cast<int16_t*>(dst) = sat16(f0[e][i]);
-                        else if (EPI == EPI_U8)
-                            *reinterpret_cast<uint8_t*>(dst) = sat8(f0[e][i]);
-                        else
-                            *reinterpret_cast<float*>(dst) = f0[e][i];
+                            v[e] = sat16(f0[e][i] * rcp);                                  // DF.cpp:296
+                        } else
+                            v[e] = sat16(f0[e][i]);
+                    }
+                    char* dst = ob + ooff;
+                    if ((reinterpret_cast<uintptr_t>(dst) & 3u) == 0)
+                        *reinterpret_cast<unsigned*>(dst) = (unsigned)(unsigned short)v[0] | ((unsigned)(unsigned short)v[1] << 16);
+                    else { reinterpret_cast<int16_t*>(dst)[0] = v[0]; reinterpret_cast<int16_t*>(dst)[1] = v[1]; }
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 2; e++) {
+                        if (col + e < a.nscan) {
+                            char* dst = ob + ooff + (unsigned)(e * a.out_cn * esz);
+                            if (EPI == EPI_WLS_CONF) {
+                                const float rcp = 1.0f / (f1[e][i] + ADF_EPS);             // DF.cpp:295
+                                *reinterpret_cast<int16_t*>(dst) = sat16(f0[e][i] * rcp);  // DF.cpp:296
+                            } else if (EPI == EPI_I16)
+                                *reinterpret_cast<int16_t*>(dst) = sat16(f0[e][i]);
+                            else if (EPI == EPI_U8)
+                                *reinterpret_cast<uint8_t*>(dst) = sat8(f0[e][i]);
+                            else
+                                *reinterpret_cast<float*>(dst) = f0[e][i];
+                        }
                     }
                 }
             }

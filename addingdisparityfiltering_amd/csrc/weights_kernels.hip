@@ -6,9 +6,9 @@
 //                 (FGS.cpp:663-675): a device expf differs in the last bits and the error would be
 //                 amplified by lambda.  768 KB, L2-resident.
 //
-// One block = one 64 x 32 tile of the guide ROI staged in LDS as bytes; each plane is written
-// either in natural [rh][pw] or transposed [rw][ph] orientation (through an LDS tile) so that the
-// pass that consumes it reads 256-byte rows.
+// One block = one 64 x 32 tile of the guide ROI staged in LDS (aligned dword loads); Cvert is written
+// row-major [rh][pw]; Chor row-major for the wave solver or transposed [rw][ph] (through an LDS tile)
+// for the exact solver, whose horizontal sweep wants the row index fastest.
 #include "adf_internal.h"
 
 namespace adf {
@@ -20,60 +20,68 @@ constexpr int TX = 64, TY = 32, NT = 256;
 template <int CH>
 __global__ void __launch_bounds__(NT) weights_kernel(WeightArgs a)
 {
-    __shared__ unsigned char gt[(TY + 1) * (TX + 1) * CH + 16];
+    // guide tile staged as 32-bit words: each staged row starts at the 4-byte boundary at or below its
+    // first needed byte (`mis[r]` = bytes skipped) so the global loads are aligned dword loads
+    constexpr int RB = (TX + 1) * CH;              // bytes needed per staged row
+    constexpr int RW = (RB + 3) / 4 + 1;           // words per staged row
+    __shared__ unsigned gw[(TY + 1) * RW];
+    __shared__ int mis[TY + 1];
     __shared__ float th[TX * (TY + 1)];
-    __shared__ float tv[TX * (TY + 1)];
     const Geom& g = a.g;
     const int tid = threadIdx.x, tx = tid % TX, ty = tid / TX;
     const int x0 = blockIdx.x * TX, y0 = blockIdx.y * TY; // ROI coordinates
     const size_t pz = blockIdx.z;
     const unsigned char* gp = a.guide + (ptrdiff_t)pz * a.pair_stride;
-    constexpr int RB = (TX + 1) * CH; // bytes per staged row
+    // bytes actually needed from each row: pixels x0 .. min(x0+TX, rw-1) (the right neighbour of the
+    // ROI's last column is never used: its weight is forced to 0, FGS.cpp:614)
+    const int last_px = min(x0 + TX, g.rw - 1);
+    const int need = (last_px - x0 + 1) * CH;
 
-    for (int idx = tid; idx < (TY + 1) * RB; idx += NT) {
-        const int rr = idx / RB, b = idx - rr * RB;
-        const int c = b / CH, k = b - c * CH;
-        const int gi = min(y0 + rr, g.rh - 1), gj = min(x0 + c, g.rw - 1);
-        gt[idx] = gp[(ptrdiff_t)(g.ry + gi) * a.stride + (ptrdiff_t)(g.rx + gj) * CH + k];
+    for (int rr = ty; rr < TY + 1; rr += NT / TX) {
+        const int gi = min(y0 + rr, g.rh - 1);
+        const unsigned char* rowp = gp + (ptrdiff_t)(g.ry + gi) * a.stride + (ptrdiff_t)(g.rx + x0) * CH;
+        const int m = (int)(reinterpret_cast<uintptr_t>(rowp) & 3u);
+        const unsigned* wp = reinterpret_cast<const unsigned*>(rowp - m);
+        const int nw = (m + need + 3) >> 2;
+        for (int w = tx; w < nw; w += TX) gw[rr * RW + w] = wp[w];
+        if (tx == 0) mis[rr] = m;
     }
     __syncthreads();
 
+    const unsigned char* gb = reinterpret_cast<const unsigned char*>(gw);
     float* chor = a.chor + pz * g.plane;
     float* cvert = a.cvert + pz * g.plane;
 #pragma unroll
     for (int kk = 0; kk < TY / 4; kk++) {
         const int r = ty + 4 * kk;
         const int i = y0 + r, j = x0 + tx;
-        const unsigned char* p = gt + r * RB + tx * CH;
-        int hidx = 0, vidx = 0;
-#pragma unroll
-        for (int c = 0; c < CH; c++) {
-            const int dh = (int)p[c] - (int)p[CH + c];
-            const int dv = (int)p[c] - (int)p[RB + c];
-            hidx += dh * dh; vidx += dv * dv;
-        }
         const bool ok = i < g.rh && j < g.rw;
         float wh = 0.0f, wv = 0.0f;
         if (ok) {
+            const unsigned char* p = gb + r * (RW * 4) + mis[r] + tx * CH;
+            const unsigned char* pd = gb + (r + 1) * (RW * 4) + mis[r + 1] + tx * CH;
+            int hidx = 0, vidx = 0;
+#pragma unroll
+            for (int c = 0; c < CH; c++) {
+                const int v = p[c];
+                const int dh = v - (int)p[CH + c];
+                const int dv = v - (int)pd[c];
+                hidx += dh * dh; vidx += dv * dv;
+            }
             wh = (j == g.rw - 1) ? 0.0f : a.lut[hidx]; // FGS.cpp:614
             wv = (i == g.rh - 1) ? 0.0f : a.lut[vidx]; // FGS.cpp:658-660
         }
         if (a.chor_orient == ORIENT_N) { if (ok) chor[(size_t)i * g.pw + j] = wh; }
         else th[tx * (TY + 1) + r] = wh;
-        if (a.cvert_orient == ORIENT_N) { if (ok) cvert[(size_t)i * g.pw + j] = wv; }
-        else tv[tx * (TY + 1) + r] = wv;
+        if (ok) cvert[(size_t)i * g.pw + j] = wv;        // Cvert is consumed row-major by both solvers
     }
-    if (a.chor_orient == ORIENT_T || a.cvert_orient == ORIENT_T) {
+    if (a.chor_orient == ORIENT_T) {
         __syncthreads();
 #pragma unroll
         for (int m = 0; m < TX / 8; m++) {
             const int cidx = tid / TY + 8 * m, ridx = tid % TY;
             const int jj = x0 + cidx, ii = y0 + ridx;
-            if (jj < g.rw && ii < g.rh) {
-                const size_t o = (size_t)jj * g.ph + ii;
-                if (a.chor_orient == ORIENT_T) chor[o] = th[cidx * (TY + 1) + ridx];
-                if (a.cvert_orient == ORIENT_T) cvert[o] = tv[cidx * (TY + 1) + ridx];
-            }
+            if (jj < g.rw && ii < g.rh) chor[(size_t)jj * g.ph + ii] = th[cidx * (TY + 1) + ridx];
         }
     }
 }
@@ -82,6 +90,7 @@ __global__ void __launch_bounds__(NT) weights_kernel(WeightArgs a)
 
 hipError_t launch_weights(const WeightArgs& a, int n_pairs, hipStream_t st)
 {
+    if (a.cvert_orient != ORIENT_N) return hipErrorInvalidValue;
     dim3 grid((a.g.rw + TX - 1) / TX, (a.g.rh + TY - 1) / TY, n_pairs);
     if (a.ch == 1) hipLaunchKernelGGL(weights_kernel<1>, grid, dim3(NT), 0, st, a);
     else if (a.ch == 3) hipLaunchKernelGGL(weights_kernel<3>, grid, dim3(NT), 0, st, a);

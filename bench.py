@@ -45,28 +45,38 @@ def parse_args():
 
 
 def cpu_baseline(view, dl, dr, roi, radius, seconds):
-    """Time the CPU oracle like perf_disparity_wls_filter.cpp:86-90 (filter built inside the loop)."""
-    import numpy as np
+    """Time the CPU oracle like perf_disparity_wls_filter.cpp:86-90 (filter built inside the loop).
+
+    The stripe count (= thread count, DF.cpp:158) that is fastest on this host is not known in
+    advance, so a few candidates share the time budget and the best one is reported."""
     import oracle
 
-    threads = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    avail = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    cands = sorted({t for t in (8, 16, 32, 64, avail) if t <= avail} or {1})
     n = view.shape[0]
-    p = oracle.default_params(sigma_color=1.5, disc_radius=radius, threads=threads)
-    p.lambda_ = 8000.0
-    oracle.wls_filter(dl[0], view[0], dr[0], roi, p, want_conf=True)  # warm-up cycle
-    cycles, t0 = 0, time.perf_counter()
-    while True:
-        k = cycles % n
-        oracle.wls_filter(dl[k], view[k], dr[k], roi, p, want_conf=True)
-        cycles += 1
-        el = time.perf_counter() - t0
-        if el >= seconds or cycles >= 200:
-            break
     H, W = dl.shape[1:]
+    best, tried = None, []
+    for threads in cands:
+        p = oracle.default_params(sigma_color=1.5, disc_radius=radius, threads=threads)
+        p.lambda_ = 8000.0
+        oracle.wls_filter(dl[0], view[0], dr[0], roi, p, want_conf=True)  # warm-up cycle
+        cycles, t0 = 0, time.perf_counter()
+        while True:
+            k = cycles % n
+            oracle.wls_filter(dl[k], view[k], dr[k], roi, p, want_conf=True)
+            cycles += 1
+            el = time.perf_counter() - t0
+            if el >= seconds / len(cands) or cycles >= 200:
+                break
+        rate = cycles * W * H / el / 1e6
+        tried.append("%d thr: %.1f Mpx/s (%d calls, %.1f s)" % (threads, rate, cycles, el))
+        if best is None or rate > best[0]:
+            best = (rate, threads)
     return {
-        "value": round(cycles * W * H / el / 1e6, 3), "unit": "Mpixels/s", "cores": threads, "kind": "port",
-        "sample": "%d filter calls over %d pair(s) of %dx%d (same inputs/params as the GPU run), %.1f s, "
-                  "oracle/adf_oracle.c scalar order, %d pthread stripes" % (cycles, n, W, H, el, threads),
+        "value": round(best[0], 3), "unit": "Mpixels/s", "cores": best[1], "kind": "port",
+        "sample": "DisparityWLSFilter on %d pair(s) of %dx%d, same inputs/params as the GPU run; oracle/adf_oracle.c "
+                  "(scalar order, pthread stripes); %d logical CPUs visible; tried %s"
+                  % (n, W, H, avail, "; ".join(tried)),
     }
 
 
