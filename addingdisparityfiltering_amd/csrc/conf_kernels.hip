@@ -100,6 +100,81 @@ __global__ void __launch_bounds__(NT) discontinuity_kernel(DiscArgs a)
 }
 
 // ---------------------------------------------------------------------------------------
+// Depth-discontinuity maps, fast path for radius <= 8 (every radius the matcher factories derive:
+// ceil(0.33*wsize) / ceil(0.5*wsize), DF.cpp:402,408; default 5).  One block walks down a strip of
+// 256-2R output columns: every row is loaded once (coalesced), exchanged through a double-buffered
+// LDS row, reduced horizontally by each thread (2R+1 LDS reads), and folded into vertical running
+// sums whose 2R+1-deep history lives in registers (the row loop is unrolled by the window height so
+// ring slots are compile-time).  All sums are exact 32-bit integers: the sum of squares is kept as
+// sum(d^2 >> 16) and sum(d^2 & 0xffff) and recombined in double.
+// ---------------------------------------------------------------------------------------
+constexpr int DC_ROWS = 128; // output rows per block
+
+template <int RT>
+__global__ void __launch_bounds__(NT) discontinuity_col_kernel(DiscArgs a)
+{
+    constexpr int K = 2 * RT + 1;
+    constexpr int OUTW = NT - 2 * RT;
+    __shared__ int rowbuf[2][NT];
+    const int tid = threadIdx.x;
+    const int view = blockIdx.z & 1;
+    const size_t pz = blockIdx.z >> 1;
+    const int x_out0 = blockIdx.x * OUTW, y_out0 = blockIdx.y * DC_ROWS;
+    const char* base = reinterpret_cast<const char*>(a.disp[view]) + (ptrdiff_t)pz * a.pair_stride[view];
+    const int rx = a.rx[view];
+    const int gx_in = reflect101(x_out0 - RT + tid, a.rw);       // input column of this thread
+    const int gx_out = x_out0 + tid - RT;                        // output column (threads RT .. NT-RT-1)
+    const bool writer = tid >= RT && tid < NT - RT && gx_out < a.rw;
+    float* dst = a.dst[view] + pz * a.frame + (size_t)a.ry * a.W + rx + gx_out;
+    const int nrows = min(DC_ROWS, a.rh - y_out0) + 2 * RT;      // input rows this block consumes
+    const double scale = 1.0 / ((double)K * (double)K);
+
+    auto load = [&](int n) -> int {                              // input row n of the block (reflected)
+        const int gy = reflect101(y_out0 - RT + n, a.rh);
+        return reinterpret_cast<const int16_t*>(base + (ptrdiff_t)(a.ry + gy) * a.stride[view])[rx + gx_in];
+    };
+
+    int r1[K], rlo[K], rhi[K];
+    int S1 = 0, Slo = 0, Shi = 0;
+    int nxt[K];
+#pragma unroll
+    for (int s = 0; s < K; s++) nxt[s] = (s < nrows) ? load(s) : 0;
+    for (int n0 = 0; n0 < nrows; n0 += K) {
+        int cur[K];
+#pragma unroll
+        for (int s = 0; s < K; s++) { cur[s] = nxt[s]; nxt[s] = (n0 + K + s < nrows) ? load(n0 + K + s) : 0; }
+#pragma unroll
+        for (int s = 0; s < K; s++) {
+            const int n = n0 + s;
+            if (n < nrows) {                                     // block-uniform
+                rowbuf[n & 1][tid] = cur[s];
+                __syncthreads();
+                int h1 = 0, hlo = 0, hhi = 0;
+                if (tid >= RT && tid < NT - RT) {
+#pragma unroll
+                    for (int d = -RT; d <= RT; d++) {
+                        const int v = rowbuf[n & 1][tid + d];
+                        const int q = v * v;                      // <= 2^30
+                        h1 += v; hlo += q & 0xffff; hhi += q >> 16;
+                    }
+                }
+                if (n >= K) { S1 -= r1[s]; Slo -= rlo[s]; Shi -= rhi[s]; } // row n-K leaves the window
+                r1[s] = h1; rlo[s] = hlo; rhi[s] = hhi;
+                S1 += h1; Slo += hlo; Shi += hhi;
+                if (n >= 2 * RT && writer) {                     // window rows n-2RT..n are complete
+                    const int oy = y_out0 + n - 2 * RT;
+                    const float mean = (float)((double)S1 * scale);
+                    const float sq = (float)(((double)Shi * 65536.0 + (double)Slo) * scale);
+                    const float variance = sq - mean * mean;      // DF.cpp:369
+                    const float v = 1.0f - a.roll_off * variance; // DF.cpp:370
+                    dst[(size_t)oy * a.W] = v < 0.0f ? 0.0f : v;
+                }
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------
 // LRC + x255 + prologue.  Grid covers the full frame so the confidence plane is written
 // exactly once everywhere (zero outside the ROI, DF.cpp:187-190,209).
 // ---------------------------------------------------------------------------------------
@@ -238,8 +313,21 @@ int max_disc_radius() { return MAX_RADIUS; }
 hipError_t launch_discontinuity(const DiscArgs& a, int n_pairs, hipStream_t st)
 {
     if (a.rw <= 0 || a.rh <= 0 || n_pairs <= 0) return hipSuccess;
-    static_assert(TX == 64 && TY == 32 && NT == 256, "discontinuity_kernel assumes a 64x32 tile and 256 threads");
     if (a.radius < 0 || a.radius > MAX_RADIUS) return hipErrorInvalidValue;
+    if (a.radius <= 8) {
+        dim3 grid(1, (a.rh + DC_ROWS - 1) / DC_ROWS, 2 * n_pairs);
+#define ADF_DC(RR)                                                                             \
+    case RR:                                                                                   \
+        grid.x = (a.rw + (NT - 2 * RR) - 1) / (NT - 2 * RR);                                   \
+        hipLaunchKernelGGL(discontinuity_col_kernel<RR>, grid, dim3(NT), 0, st, a);            \
+        break;
+        switch (a.radius) {
+            ADF_DC(0) ADF_DC(1) ADF_DC(2) ADF_DC(3) ADF_DC(4) ADF_DC(5) ADF_DC(6) ADF_DC(7) ADF_DC(8)
+        }
+#undef ADF_DC
+        return hipGetLastError();
+    }
+    static_assert(TX == 64 && TY == 32 && NT == 256, "discontinuity_kernel assumes a 64x32 tile and 256 threads");
     const size_t lds = disc_lds_bytes(a.radius);
     static size_t configured = 0;
     if (lds > 48 * 1024 && lds > configured) {

@@ -16,6 +16,7 @@ namespace adf {
 namespace {
 
 constexpr int TX = 64, TY = 32, NT = 256;
+constexpr int LUT_HEAD = 2048;
 
 template <int CH>
 __global__ void __launch_bounds__(NT) weights_kernel(WeightArgs a)
@@ -27,6 +28,10 @@ __global__ void __launch_bounds__(NT) weights_kernel(WeightArgs a)
     __shared__ unsigned gw[(TY + 1) * RW];
     __shared__ int mis[TY + 1];
     __shared__ float th[TX * (TY + 1)];
+    // the head of the LUT (small colour differences: the overwhelmingly common case) is cached in LDS:
+    // a 64-lane gather from the global table costs one L1 tag lookup per distinct line, the same
+    // gather from LDS a few cycles.  Larger indices fall back to the global table.
+    __shared__ float lut_head[LUT_HEAD];
     const Geom& g = a.g;
     const int tid = threadIdx.x, tx = tid % TX, ty = tid / TX;
     const int x0 = blockIdx.x * TX, y0 = blockIdx.y * TY; // ROI coordinates
@@ -46,6 +51,7 @@ __global__ void __launch_bounds__(NT) weights_kernel(WeightArgs a)
         for (int w = tx; w < nw; w += TX) gw[rr * RW + w] = wp[w];
         if (tx == 0) mis[rr] = m;
     }
+    for (int q = tid; q < LUT_HEAD; q += NT) lut_head[q] = a.lut[q];
     __syncthreads();
 
     const unsigned char* gb = reinterpret_cast<const unsigned char*>(gw);
@@ -68,8 +74,10 @@ __global__ void __launch_bounds__(NT) weights_kernel(WeightArgs a)
                 const int dv = v - (int)pd[c];
                 hidx += dh * dh; vidx += dv * dv;
             }
-            wh = (j == g.rw - 1) ? 0.0f : a.lut[hidx]; // FGS.cpp:614
-            wv = (i == g.rh - 1) ? 0.0f : a.lut[vidx]; // FGS.cpp:658-660
+            wh = hidx < LUT_HEAD ? lut_head[hidx] : a.lut[hidx];
+            wv = vidx < LUT_HEAD ? lut_head[vidx] : a.lut[vidx];
+            if (j == g.rw - 1) wh = 0.0f;              // FGS.cpp:614
+            if (i == g.rh - 1) wv = 0.0f;              // FGS.cpp:658-660
         }
         if (a.chor_orient == ORIENT_N) { if (ok) chor[(size_t)i * g.pw + j] = wh; }
         else th[tx * (TY + 1) + r] = wh;
