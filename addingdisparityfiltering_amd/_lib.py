@@ -7,7 +7,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libadf_wls.so")
+# ADF_WLS_LIB selects another build of the same library (A/B experiments with compile-time knobs)
+LIB_PATH = os.environ.get("ADF_WLS_LIB") or os.path.join(_HERE, "libadf_wls.so")
 
 ADF_OK, ADF_EBADARG, ADF_ESIZE, ADF_EHIP, ADF_ENOMEM, ADF_ENODEV = range(6)
 SOLVER_EXACT, SOLVER_WAVE = 0, 1

@@ -21,6 +21,25 @@ FLAGS = ["-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-ffp-contract=o
          "-fno-fast-math", "-Wall", "-Wno-unused-function", "-Wno-unused-value"]
 
 
+def build_variant(name, defines, verbose=False):
+    """Build libadf_wls_<name>.so with extra -D flags (experiments; selected with ADF_WLS_LIB)."""
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    objdir = os.path.join(_HERE, "build", name)
+    os.makedirs(objdir, exist_ok=True)
+    out = os.path.join(_HERE, "libadf_wls_%s.so" % name)
+    procs, objs = [], []
+    for src, extra in SOURCES.items():
+        obj = os.path.join(objdir, src.replace(".hip", ".o"))
+        objs.append(obj)
+        cmd = [hipcc] + FLAGS + extra + ["-D" + d for d in defines] + ["-c", os.path.join(CSRC, src), "-o", obj]
+        procs.append((cmd, subprocess.Popen(cmd, cwd=CSRC)))
+    for cmd, p in procs:
+        if p.wait() != 0:
+            raise subprocess.CalledProcessError(p.returncode, cmd)
+    subprocess.run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", out] + objs, check=True, cwd=CSRC)
+    return out
+
+
 def build_native(force=False, verbose=False):
     hdrs = [os.path.join(CSRC, h) for h in HEADERS] + [os.path.join(_HERE, "..", "include", "adf_wls.h")]
     hdr_m = max(os.path.getmtime(h) for h in hdrs)

@@ -134,18 +134,23 @@ __global__ void __launch_bounds__(NT) discontinuity_col_kernel(DiscArgs a)
         return reinterpret_cast<const int16_t*>(base + (ptrdiff_t)(a.ry + gy) * a.stride[view])[rx + gx_in];
     };
 
+    // rows are consumed in groups of U (a multiple of the window height K, so that ring slots stay
+    // compile-time) and the next group's U loads are in flight while the current group is reduced
+    constexpr int U = K * ((16 + K - 1) / K);
     int r1[K], rlo[K], rhi[K];
     int S1 = 0, Slo = 0, Shi = 0;
-    int nxt[K];
+    int nxt[U];
 #pragma unroll
-    for (int s = 0; s < K; s++) nxt[s] = (s < nrows) ? load(s) : 0;
-    for (int n0 = 0; n0 < nrows; n0 += K) {
-        int cur[K];
+    for (int s = 0; s < U; s++) nxt[s] = (s < nrows) ? load(s) : 0;
+    for (int n0 = 0; n0 < nrows; n0 += U) {
+        int cur[U];
 #pragma unroll
-        for (int s = 0; s < K; s++) { cur[s] = nxt[s]; nxt[s] = (n0 + K + s < nrows) ? load(n0 + K + s) : 0; }
+        for (int s = 0; s < U; s++) { cur[s] = nxt[s]; nxt[s] = (n0 + U + s < nrows) ? load(n0 + U + s) : 0; }
 #pragma unroll
-        for (int s = 0; s < K; s++) {
+        for (int s = 0; s < U; s++) {
             const int n = n0 + s;
+            constexpr int dummy = 0; (void)dummy;
+            const int slot = s % K;                               // compile-time after unrolling
             if (n < nrows) {                                     // block-uniform
                 rowbuf[n & 1][tid] = cur[s];
                 __syncthreads();
@@ -158,8 +163,8 @@ __global__ void __launch_bounds__(NT) discontinuity_col_kernel(DiscArgs a)
                         h1 += v; hlo += q & 0xffff; hhi += q >> 16;
                     }
                 }
-                if (n >= K) { S1 -= r1[s]; Slo -= rlo[s]; Shi -= rhi[s]; } // row n-K leaves the window
-                r1[s] = h1; rlo[s] = hlo; rhi[s] = hhi;
+                if (n >= K) { S1 -= r1[slot]; Slo -= rlo[slot]; Shi -= rhi[slot]; } // row n-K leaves the window
+                r1[slot] = h1; rlo[slot] = hlo; rhi[slot] = hhi;
                 S1 += h1; Slo += hlo; Shi += hhi;
                 if (n >= 2 * RT && writer) {                     // window rows n-2RT..n are complete
                     const int oy = y_out0 + n - 2 * RT;

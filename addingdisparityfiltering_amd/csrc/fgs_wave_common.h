@@ -60,67 +60,75 @@ __device__ __forceinline__ void launder(float (&v)[M])
     for (int i = 0; i < M; i++) asm volatile("" : "+v"(v[i]));
 }
 
-// Phase 1 for NC independent chunks (columns) interleaved: boundary coefficients with O(1) state.
+// Reciprocal used inside the sweeps.  v_rcp_f32 is accurate to 1 ulp; one Newton step makes it
+// (nearly) correctly rounded at the price of two more dependent FMAs on the serial chain.
+template <bool REFINE>
+__device__ __forceinline__ float rcp_sel(float x) { return REFINE ? rcp_nr(x) : __builtin_amdgcn_rcpf(x); }
+
+#ifndef ADF_WAVE_REFINE_BOUNDARY
+#define ADF_WAVE_REFINE_BOUNDARY 0
+#endif
+#ifndef ADF_WAVE_REFINE_SOLVE
+#define ADF_WAVE_REFINE_SOLVE 1
+#endif
+
+// Phase 1 for NC independent chunks (columns): boundary coefficients with O(1) state.  The
+// left->right (LU) and right->left (UL) sweeps are independent serial chains; they advance together,
+// one element each per step, so that every step carries 2*NC independent chains (the passes are bound
+// by VALU dependency stalls, not by issue slots).
 template <int M, int R, int NC>
-__device__ __forceinline__ void chunk_boundary(float (&c)[NC][M], const float (&f0)[NC][M], const float (&f1)[NC][M],
+__device__ __forceinline__ void chunk_boundary(const float (&c)[NC][M], const float (&f0)[NC][M], const float (&f1)[NC][M],
                                                const float (&a_s)[NC], Boundary<R> (&o)[NC])
 {
-    // left -> right: x_i + D_i x_{i+1} = g_i - p_i xL
-    {
-        float D[NC], g0[NC], g1[NC], p[NC];
+    constexpr bool NRB = ADF_WAVE_REFINE_BOUNDARY != 0;
+    // left -> right: x_i + D_i x_{i+1} = g_i - p_i xL;   right -> left: x_i + E_i x_{i-1} = h_i - q_i xR
+    float D[NC], g0[NC], g1[NC], p[NC];
+    float r[NC], h0[NC], h1[NC], q[NC];
 #pragma unroll
-        for (int e = 0; e < NC; e++) {
-            const float a = a_s[e];
-            const float r = rcp_nr((1.0f - a) - c[e][0]);
-            D[e] = c[e][0] * r; g0[e] = f0[e][0] * r; g1[e] = (R > 1) ? f1[e][0] * r : 0.0f; p[e] = a * r;
-        }
-#pragma unroll
-        for (int i = 1; i <= M - 2; i++) {
-#pragma unroll
-            for (int e = 0; e < NC; e++) {
-                const float a = c[e][i - 1];
-                const float b = (1.0f - a) - c[e][i];
-                const float r = rcp_nr(__builtin_fmaf(-a, D[e], b));
-                D[e] = c[e][i] * r;
-                g0[e] = __builtin_fmaf(-a, g0[e], f0[e][i]) * r;
-                if (R > 1) g1[e] = __builtin_fmaf(-a, g1[e], f1[e][i]) * r;
-                p[e] = (-a * p[e]) * r;
-                asm volatile("" : "+v"(p[e])); // p feeds nothing until the end: keep its chain in step
-            }
-            ADF_STEP_FENCE();
-        }
-#pragma unroll
-        for (int e = 0; e < NC; e++) { o[e].GE0 = g0[e]; o[e].GE1 = g1[e]; o[e].PE = p[e]; o[e].QE = D[e]; }
+    for (int e = 0; e < NC; e++) {
+        const float a = a_s[e];
+        const float rl = rcp_sel<NRB>((1.0f - a) - c[e][0]);
+        D[e] = c[e][0] * rl; g0[e] = f0[e][0] * rl; g1[e] = (R > 1) ? f1[e][0] * rl : 0.0f; p[e] = a * rl;
+        const float ci = c[e][M - 2];
+        const float ar = (M - 2 == 0) ? a_s[e] : c[e][(M - 3 > 0) ? M - 3 : 0];
+        r[e] = rcp_sel<NRB>((1.0f - ar) - ci);
+        h0[e] = f0[e][M - 2] * r[e]; h1[e] = (R > 1) ? f1[e][M - 2] * r[e] : 0.0f; q[e] = ci * r[e];
     }
 #pragma unroll
-    for (int e = 0; e < NC; e++) launder<M>(c[e]);
-    // right -> left: x_i + E_i x_{i-1} = h_i - q_i xR
-    {
-        float r[NC], h0[NC], h1[NC], q[NC];
+    for (int t = 1; t <= M - 2; t++) {
+        const int i = t, j = M - 2 - t; // LU element, UL element
 #pragma unroll
         for (int e = 0; e < NC; e++) {
-            const float ci = c[e][M - 2];
-            const float a = (M - 2 == 0) ? a_s[e] : c[e][(M - 3 > 0) ? M - 3 : 0];
-            r[e] = rcp_nr((1.0f - a) - ci);
-            h0[e] = f0[e][M - 2] * r[e]; h1[e] = (R > 1) ? f1[e][M - 2] * r[e] : 0.0f; q[e] = ci * r[e];
-        }
-#pragma unroll
-        for (int i = M - 3; i >= 0; i--) {
-#pragma unroll
-            for (int e = 0; e < NC; e++) {
-                const float ci = c[e][i];
-                const float a = (i == 0) ? a_s[e] : c[e][(i > 0) ? i - 1 : 0];
+            {
+                const float a = c[e][i - 1];
+                const float b = (1.0f - a) - c[e][i];
+                const float rl = rcp_sel<NRB>(__builtin_fmaf(-a, D[e], b));
+                D[e] = c[e][i] * rl;
+                g0[e] = __builtin_fmaf(-a, g0[e], f0[e][i]) * rl;
+                if (R > 1) g1[e] = __builtin_fmaf(-a, g1[e], f1[e][i]) * rl;
+                p[e] = (-a * p[e]) * rl;
+                asm volatile("" : "+v"(p[e])); // p feeds nothing until the end: keep its chain in step
+            }
+            {
+                // opaque copies: without them the compiler shares b_j = 1 - a_j - c_j between the two
+                // sweeps and keeps it alive from one sweep's visit of j to the other's
+                float ci = c[e][j];
+                float a = (j == 0) ? a_s[e] : c[e][(j > 0) ? j - 1 : 0];
+                asm volatile("" : "+v"(ci), "+v"(a));
                 const float b = (1.0f - a) - ci;
-                r[e] = rcp_nr(__builtin_fmaf(-ci * ci, r[e], b));
-                h0[e] = __builtin_fmaf(-ci, h0[e], f0[e][i]) * r[e];
-                if (R > 1) h1[e] = __builtin_fmaf(-ci, h1[e], f1[e][i]) * r[e];
+                r[e] = rcp_sel<NRB>(__builtin_fmaf(-ci * ci, r[e], b));
+                h0[e] = __builtin_fmaf(-ci, h0[e], f0[e][j]) * r[e];
+                if (R > 1) h1[e] = __builtin_fmaf(-ci, h1[e], f1[e][j]) * r[e];
                 q[e] = (-ci * q[e]) * r[e];
                 asm volatile("" : "+v"(q[e]));
             }
-            ADF_STEP_FENCE();
         }
+        ADF_STEP_FENCE();
+    }
 #pragma unroll
-        for (int e = 0; e < NC; e++) { o[e].GS0 = h0[e]; o[e].GS1 = h1[e]; o[e].PS = a_s[e] * r[e]; o[e].QS = q[e]; }
+    for (int e = 0; e < NC; e++) {
+        o[e].GE0 = g0[e]; o[e].GE1 = g1[e]; o[e].PE = p[e]; o[e].QE = D[e];
+        o[e].GS0 = h0[e]; o[e].GS1 = h1[e]; o[e].PS = a_s[e] * r[e]; o[e].QS = q[e];
     }
 }
 
@@ -130,6 +138,7 @@ __device__ __forceinline__ void chunk_solve(float (&c)[NC][M], float (&f0)[NC][M
                                             const float (&a_s)[NC], const float (&xL0)[NC], const float (&xL1)[NC],
                                             const float (&xR0)[NC], const float (&xR1)[NC])
 {
+    constexpr bool NRS = ADF_WAVE_REFINE_SOLVE != 0;
 #pragma unroll
     for (int e = 0; e < NC; e++) launder<M>(c[e]);
     float corig[NC], D[NC], g0[NC], g1[NC];
@@ -137,7 +146,7 @@ __device__ __forceinline__ void chunk_solve(float (&c)[NC][M], float (&f0)[NC][M
     for (int e = 0; e < NC; e++) {
         const float a = a_s[e];
         corig[e] = c[e][0];
-        const float r = rcp_nr((1.0f - a) - corig[e]);
+        const float r = rcp_sel<NRS>((1.0f - a) - corig[e]);
         D[e] = corig[e] * r;
         g0[e] = __builtin_fmaf(-a, xL0[e], f0[e][0]) * r;
         g1[e] = (R > 1) ? __builtin_fmaf(-a, xL1[e], f1[e][0]) * r : 0.0f;
@@ -150,7 +159,7 @@ __device__ __forceinline__ void chunk_solve(float (&c)[NC][M], float (&f0)[NC][M
             const float a = corig[e];
             corig[e] = c[e][i];
             const float b = (1.0f - a) - corig[e];
-            const float r = rcp_nr(__builtin_fmaf(-a, D[e], b));
+            const float r = rcp_sel<NRS>(__builtin_fmaf(-a, D[e], b));
             D[e] = corig[e] * r;
             g0[e] = __builtin_fmaf(-a, g0[e], f0[e][i]) * r;
             if (R > 1) g1[e] = __builtin_fmaf(-a, g1[e], f1[e][i]) * r;

@@ -74,8 +74,10 @@ __global__ void __launch_bounds__(NT) weights_kernel(WeightArgs a)
                 const int dv = v - (int)pd[c];
                 hidx += dh * dh; vidx += dv * dv;
             }
-            wh = hidx < LUT_HEAD ? lut_head[hidx] : a.lut[hidx];
-            wv = vidx < LUT_HEAD ? lut_head[vidx] : a.lut[vidx];
+            // explicit branches: a ?: between an LDS and a global address would be lowered to a select
+            // of flat pointers and a (slow) flat load per gather
+            if (hidx < LUT_HEAD) wh = lut_head[hidx]; else wh = a.lut[hidx];
+            if (vidx < LUT_HEAD) wv = lut_head[vidx]; else wv = a.lut[vidx];
             if (j == g.rw - 1) wh = 0.0f;              // FGS.cpp:614
             if (i == g.rh - 1) wv = 0.0f;              // FGS.cpp:658-660
         }
