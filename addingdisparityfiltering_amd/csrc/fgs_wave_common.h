@@ -66,7 +66,7 @@ template <bool REFINE>
 __device__ __forceinline__ float rcp_sel(float x) { return REFINE ? rcp_nr(x) : __builtin_amdgcn_rcpf(x); }
 
 #ifndef ADF_WAVE_REFINE_BOUNDARY
-#define ADF_WAVE_REFINE_BOUNDARY 0
+#define ADF_WAVE_REFINE_BOUNDARY 1
 #endif
 #ifndef ADF_WAVE_REFINE_SOLVE
 #define ADF_WAVE_REFINE_SOLVE 1
@@ -81,6 +81,14 @@ __device__ __forceinline__ void chunk_boundary(const float (&c)[NC][M], const fl
                                                const float (&a_s)[NC], Boundary<R> (&o)[NC])
 {
     constexpr bool NRB = ADF_WAVE_REFINE_BOUNDARY != 0;
+#ifdef ADF_WAVE_DEBUG_SKIP_COMPUTE  // timing experiment only: keep the data flow, drop the sweeps
+#pragma unroll
+    for (int e = 0; e < NC; e++) {
+        o[e].GE0 = f0[e][0]; o[e].GE1 = f1[e][0]; o[e].PE = c[e][0]; o[e].QE = c[e][M - 1];
+        o[e].GS0 = f0[e][M - 1]; o[e].GS1 = f1[e][M - 1]; o[e].PS = a_s[e]; o[e].QS = c[e][1];
+    }
+    return;
+#endif
     // left -> right: x_i + D_i x_{i+1} = g_i - p_i xL;   right -> left: x_i + E_i x_{i-1} = h_i - q_i xR
     float D[NC], g0[NC], g1[NC], p[NC];
     float r[NC], h0[NC], h1[NC], q[NC];
@@ -139,6 +147,16 @@ __device__ __forceinline__ void chunk_solve(float (&c)[NC][M], float (&f0)[NC][M
                                             const float (&xR0)[NC], const float (&xR1)[NC])
 {
     constexpr bool NRS = ADF_WAVE_REFINE_SOLVE != 0;
+#ifdef ADF_WAVE_DEBUG_SKIP_COMPUTE
+#pragma unroll
+    for (int e = 0; e < NC; e++)
+#pragma unroll
+        for (int i = 0; i < M; i++) {
+            f0[e][i] = __builtin_fmaf(c[e][i], xR0[e] + xL0[e], f0[e][i]);
+            f1[e][i] = __builtin_fmaf(c[e][i], xR1[e] + xL1[e], f1[e][i]);
+        }
+    return;
+#endif
 #pragma unroll
     for (int e = 0; e < NC; e++) launder<M>(c[e]);
     float corig[NC], D[NC], g0[NC], g1[NC];

@@ -24,16 +24,17 @@ __global__ void __launch_bounds__(VT) wave_vpass_kernel(WavePassArgs a)
     __shared__ float xs[2][VC][64];   // separator solutions
     const int tid = threadIdx.x;
     const int xp = tid & 7, cidx = tid >> 3;
-    // A strip row is a 64-byte half of a 128-byte line; the other half belongs to the next strip.
-    // Blocks b and b+8 are dealt to the same XCD back to back (speed only, never correctness), so the
-    // two strips of a line pair are mapped to blocks b, b+8: the second request for a line then hits
-    // (or merges in) that XCD's L2 instead of fetching the line from the fabric a second time.
+    // A strip row is a 64-byte half of a 128-byte line of the float planes (and a 32-byte quarter of a
+    // line of the int16 output); the rest of the line belongs to the neighbouring strips.  Blocks b,
+    // b+8, b+16, b+24 are dealt to the same XCD back to back (speed only, never correctness), so four
+    // consecutive strips are mapped to them: later requests for a line hit (or merge in) that XCD's L2
+    // instead of going to the fabric again, and partial-line writes combine there before eviction.
     int strip = blockIdx.x;
     {
-        const int nfull = (int)(gridDim.x / 16) * 16;
+        const int nfull = (int)(gridDim.x / 32) * 32;
         if ((int)blockIdx.x < nfull) {
-            const int grp = blockIdx.x >> 4, w = blockIdx.x & 15;
-            strip = (grp << 4) + ((w & 7) << 1) + (w >> 3);
+            const int grp = blockIdx.x >> 5, w = blockIdx.x & 31;
+            strip = (grp << 5) + ((w & 7) << 2) + (w >> 3);
         }
     }
     const int col = strip * VC + 2 * xp;             // < pitch by construction of the grid

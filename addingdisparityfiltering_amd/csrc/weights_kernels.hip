@@ -57,33 +57,52 @@ __global__ void __launch_bounds__(NT) weights_kernel(WeightArgs a)
     const unsigned char* gb = reinterpret_cast<const unsigned char*>(gw);
     float* chor = a.chor + pz * g.plane;
     float* cvert = a.cvert + pz * g.plane;
+    // Everything up to the stores is unconditional: staged bytes outside the ROI are stale LDS, but any
+    // byte triple still indexes inside the 3*255^2+1-entry table, and their results are never stored.
+    // Batched that way the LDS reads and table gathers of a thread's 8 pixels overlap instead of each
+    // waiting for the previous pixel's.
+    int hidx[TY / 4], vidx[TY / 4];
 #pragma unroll
     for (int kk = 0; kk < TY / 4; kk++) {
         const int r = ty + 4 * kk;
-        const int i = y0 + r, j = x0 + tx;
-        const bool ok = i < g.rh && j < g.rw;
-        float wh = 0.0f, wv = 0.0f;
-        if (ok) {
-            const unsigned char* p = gb + r * (RW * 4) + mis[r] + tx * CH;
-            const unsigned char* pd = gb + (r + 1) * (RW * 4) + mis[r + 1] + tx * CH;
-            int hidx = 0, vidx = 0;
+        const unsigned char* p = gb + r * (RW * 4) + mis[r] + tx * CH;
+        const unsigned char* pd = gb + (r + 1) * (RW * 4) + mis[r + 1] + tx * CH;
+        int hi = 0, vi = 0;
 #pragma unroll
-            for (int c = 0; c < CH; c++) {
-                const int v = p[c];
-                const int dh = v - (int)p[CH + c];
-                const int dv = v - (int)pd[c];
-                hidx += dh * dh; vidx += dv * dv;
-            }
-            // explicit branches: a ?: between an LDS and a global address would be lowered to a select
-            // of flat pointers and a (slow) flat load per gather
-            if (hidx < LUT_HEAD) wh = lut_head[hidx]; else wh = a.lut[hidx];
-            if (vidx < LUT_HEAD) wv = lut_head[vidx]; else wv = a.lut[vidx];
-            if (j == g.rw - 1) wh = 0.0f;              // FGS.cpp:614
-            if (i == g.rh - 1) wv = 0.0f;              // FGS.cpp:658-660
+        for (int c = 0; c < CH; c++) {
+            const int v = p[c];
+            const int dh = v - (int)p[CH + c];
+            const int dv = v - (int)pd[c];
+            hi += dh * dh; vi += dv * dv;
         }
-        if (a.chor_orient == ORIENT_N) { if (ok) chor[(size_t)i * g.pw + j] = wh; }
-        else th[tx * (TY + 1) + r] = wh;
-        if (ok) cvert[(size_t)i * g.pw + j] = wv;        // Cvert is consumed row-major by both solvers
+        hidx[kk] = hi; vidx[kk] = vi;
+    }
+    float wh[TY / 4], wv[TY / 4];
+    bool big = false;
+#pragma unroll
+    for (int kk = 0; kk < TY / 4; kk++) {
+        wh[kk] = lut_head[min(hidx[kk], LUT_HEAD - 1)];
+        wv[kk] = lut_head[min(vidx[kk], LUT_HEAD - 1)];
+        big = big || hidx[kk] >= LUT_HEAD || vidx[kk] >= LUT_HEAD;
+    }
+    if (big) { // rare: strong colour edges index past the cached head of the table
+#pragma unroll
+        for (int kk = 0; kk < TY / 4; kk++) {
+            if (hidx[kk] >= LUT_HEAD) wh[kk] = a.lut[hidx[kk]];
+            if (vidx[kk] >= LUT_HEAD) wv[kk] = a.lut[vidx[kk]];
+        }
+    }
+    const int j = x0 + tx;
+#pragma unroll
+    for (int kk = 0; kk < TY / 4; kk++) {
+        const int r = ty + 4 * kk;
+        const int i = y0 + r;
+        const bool ok = i < g.rh && j < g.rw;
+        const float h = (j == g.rw - 1) ? 0.0f : wh[kk];   // FGS.cpp:614
+        const float v = (i == g.rh - 1) ? 0.0f : wv[kk];   // FGS.cpp:658-660
+        if (a.chor_orient == ORIENT_N) { if (ok) chor[(size_t)i * g.pw + j] = h; }
+        else th[tx * (TY + 1) + r] = ok ? h : 0.0f;
+        if (ok) cvert[(size_t)i * g.pw + j] = v;           // Cvert is consumed row-major by both solvers
     }
     if (a.chor_orient == ORIENT_T) {
         __syncthreads();

@@ -36,7 +36,7 @@ def parse_args():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--config", type=int, default=3, help="BASELINE.json config id (geometry)")
     ap.add_argument("--pairs", type=int, default=64, help="stereo pairs per GPU and step")
-    ap.add_argument("--solver", choices=["exact", "wave"], default=os.environ.get("ADF_BENCH_SOLVER", "exact"))
+    ap.add_argument("--solver", choices=["exact", "wave"], default=os.environ.get("ADF_BENCH_SOLVER", "wave"))
     ap.add_argument("--distribution", choices=["scatter", "local"], default="scatter",
                     help="N>1: rank 0 builds the batch and scatters it over RCCL, or each rank builds its shard")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU baseline budget (0 = skip)")
