@@ -1,0 +1,289 @@
+// adf_ximgproc.hpp -- header-only C++ adaptor: the reference's operator interface over the C-ABI.
+//
+// Mirrors cv::ximgproc for the disparity-filter path -- same class and function names, argument
+// order and meaning, defaults and error behaviour (exceptions) as
+//   modules/ximgproc/include/opencv2/ximgproc/disparity_filter.hpp  (DF.hpp:52-149)
+//   modules/ximgproc/include/opencv2/ximgproc/edge_filter.hpp       (EF.hpp:361-413)
+// so that a stereo pipeline switches by changing a namespace.  All compute happens in
+// libadf_wls.so (HIP kernels); this header only marshals cv::Mat-like images into adf_wls.h calls.
+//
+// With OpenCV available (opencv2/core.hpp on the include path) the types are cv::Mat / cv::Rect /
+// cv::Ptr and the matcher factories take cv::StereoMatcher.  Without it (this repo's CI image has no
+// OpenCV) a minimal Mat / Rect stands in and the matcher factories take the three numbers they read.
+#pragma once
+
+#include "adf_wls.h"
+
+#include <cmath>
+#include <cstring>
+#include <memory>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#if !defined(ADF_NO_OPENCV) && defined(__has_include)
+#if __has_include(<opencv2/core.hpp>)
+#include <opencv2/core.hpp>
+#define ADF_HAVE_OPENCV 1
+#if __has_include(<opencv2/calib3d.hpp>)
+#include <opencv2/calib3d.hpp>
+#define ADF_HAVE_CALIB3D 1
+#endif
+#endif
+#endif
+
+namespace adf {
+
+// cv::Exception counterpart: CV_Assert / CV_Error sites of DF.cpp:221-222,262-264, FGS.cpp:143-144,184-189.
+struct Exception : std::runtime_error {
+    int code;
+    Exception(int c, const std::string& m) : std::runtime_error(m), code(c) {}
+};
+inline void check(int rc) { if (rc != ADF_OK) throw Exception(rc, adf_last_error()); }
+
+#ifdef ADF_HAVE_OPENCV
+using Mat = cv::Mat;
+using Rect = cv::Rect;
+template <class T> using Ptr = cv::Ptr<T>;
+enum { D8U = CV_8U, D16S = CV_16S, D32F = CV_32F };
+inline int mat_depth(const Mat& m) { return m.depth(); }
+inline int mat_channels(const Mat& m) { return m.channels(); }
+inline ptrdiff_t mat_step(const Mat& m) { return (ptrdiff_t)m.step; }
+inline void mat_create(Mat& m, int rows, int cols, int depth, int cn) { m.create(rows, cols, CV_MAKETYPE(depth, cn)); }
+#else
+struct Rect {
+    int x = 0, y = 0, width = 0, height = 0;
+    Rect() {}
+    Rect(int x_, int y_, int w_, int h_) : x(x_), y(y_), width(w_), height(h_) {}
+    int area() const { return width * height; }
+};
+enum { D8U = 0, D16S = 3, D32F = 5 }; // cv depth codes
+// Minimal dense image: shared buffer, header copies share data (like cv::Mat).
+struct Mat {
+    int rows = 0, cols = 0, depth_ = D8U, cn = 1;
+    size_t step = 0;
+    unsigned char* data = nullptr;
+    std::shared_ptr<std::vector<unsigned char>> buf;
+    Mat() {}
+    Mat(int r, int c, int depth, int channels = 1) { create(r, c, depth, channels); }
+    static size_t esz(int depth) { return depth == D8U ? 1 : depth == D16S ? 2 : 4; }
+    void create(int r, int c, int depth, int channels = 1)
+    {
+        if (r == rows && c == cols && depth == depth_ && channels == cn && data) return;
+        rows = r; cols = c; depth_ = depth; cn = channels;
+        step = (size_t)c * channels * esz(depth);
+        buf = std::make_shared<std::vector<unsigned char>>(step * (size_t)r);
+        data = buf->data();
+    }
+    bool empty() const { return !data || rows == 0 || cols == 0; }
+    template <class T> T* ptr(int r = 0) { return reinterpret_cast<T*>(data + step * (size_t)r); }
+    template <class T> const T* ptr(int r = 0) const { return reinterpret_cast<const T*>(data + step * (size_t)r); }
+};
+template <class T> using Ptr = std::shared_ptr<T>;
+inline int mat_depth(const Mat& m) { return m.depth_; }
+inline int mat_channels(const Mat& m) { return m.cn; }
+inline ptrdiff_t mat_step(const Mat& m) { return (ptrdiff_t)m.step; }
+inline void mat_create(Mat& m, int rows, int cols, int depth, int cn) { m.create(rows, cols, depth, cn); }
+#endif
+
+namespace ximgproc {
+
+// DF.hpp:52-76
+class DisparityFilter {
+public:
+    virtual ~DisparityFilter() {}
+    virtual void filter(const Mat& disparity_map_left, const Mat& left_view, Mat& filtered_disparity_map,
+                        const Mat& disparity_map_right = Mat(), Rect ROI = Rect(), const Mat& right_view = Mat()) = 0;
+};
+
+// DF.hpp:82-122
+class DisparityWLSFilter : public DisparityFilter {
+public:
+    virtual double getLambda() = 0;
+    virtual void setLambda(double _lambda) = 0;
+    virtual double getSigmaColor() = 0;
+    virtual void setSigmaColor(double _sigma_color) = 0;
+    virtual int getLRCthresh() = 0;
+    virtual void setLRCthresh(int _LRC_thresh) = 0;
+    virtual int getDepthDiscontinuityRadius() = 0;
+    virtual void setDepthDiscontinuityRadius(int _disc_radius) = 0;
+    virtual Mat getConfidenceMap() = 0;
+    virtual Rect getROI() = 0;
+    // extension: ADF_SOLVER_EXACT (bit-exact scalar order) or ADF_SOLVER_WAVE (on-chip, <= 1 LSB)
+    virtual void setSolver(int solver) = 0;
+};
+
+class DisparityWLSFilterImpl : public DisparityWLSFilter {
+    adf_wls_t* h_ = nullptr;
+    bool use_confidence_;
+    int last_rows_ = 0, last_cols_ = 0;
+public:
+    DisparityWLSFilterImpl(bool use_confidence, int l, int r, int t, int b, int min_disp) : use_confidence_(use_confidence)
+    {
+        check(adf_wls_create(&h_, use_confidence ? 1 : 0, l, r, t, b, min_disp));
+    }
+    ~DisparityWLSFilterImpl() override { adf_wls_destroy(h_); }
+    DisparityWLSFilterImpl(const DisparityWLSFilterImpl&) = delete;
+    DisparityWLSFilterImpl& operator=(const DisparityWLSFilterImpl&) = delete;
+
+    void filter(const Mat& dl, const Mat& view, Mat& out, const Mat& dr, Rect ROI, const Mat&) override
+    {
+        if (dl.empty() || mat_depth(dl) != D16S || mat_channels(dl) != 1)       // DF.cpp:221
+            throw Exception(ADF_EBADARG, "disparity_map_left must be a non-empty CV_16SC1 image");
+        if (view.empty() || mat_depth(view) != D8U || (mat_channels(view) != 1 && mat_channels(view) != 3)) // :222
+            throw Exception(ADF_EBADARG, "left_view must be CV_8UC1 or CV_8UC3");
+        if (dl.rows != view.rows || dl.cols != view.cols)
+            throw Exception(ADF_ESIZE, "disparity map and view sizes differ (resize path not built)");
+        const bool have_r = !dr.empty();
+        if (use_confidence_) {                                                 // DF.cpp:262-264
+            if (!have_r || mat_depth(dr) != D16S || mat_channels(dr) != 1)
+                throw Exception(ADF_EBADARG, "disparity_map_right must be a non-empty CV_16SC1 image");
+            if (dr.rows != dl.rows || dr.cols != dl.cols)
+                throw Exception(ADF_ESIZE, "left and right disparity maps differ in size");
+        }
+        mat_create(out, dl.rows, dl.cols, D16S, 1);                            // DF.cpp:252,282
+        adf_rect roi{ROI.x, ROI.y, ROI.width, ROI.height};
+        check(adf_wls_filter_host(h_, 1, reinterpret_cast<const int16_t*>(dl.data), mat_step(dl), 0,
+                                  view.data, mat_step(view), 0, mat_channels(view), dl.cols, dl.rows,
+                                  reinterpret_cast<int16_t*>(out.data), mat_step(out), 0,
+                                  have_r ? reinterpret_cast<const int16_t*>(dr.data) : nullptr, have_r ? mat_step(dr) : 0, 0,
+                                  ROI.area() != 0 ? &roi : nullptr));
+        last_rows_ = dl.rows; last_cols_ = dl.cols;
+    }
+    double getLambda() override { double v; check(adf_wls_get_lambda(h_, &v)); return v; }
+    void setLambda(double v) override { check(adf_wls_set_lambda(h_, v)); }
+    double getSigmaColor() override { double v; check(adf_wls_get_sigma_color(h_, &v)); return v; }
+    void setSigmaColor(double v) override { check(adf_wls_set_sigma_color(h_, v)); }
+    int getLRCthresh() override { int v; check(adf_wls_get_lrc_thresh(h_, &v)); return v; }
+    void setLRCthresh(int v) override { check(adf_wls_set_lrc_thresh(h_, v)); }
+    int getDepthDiscontinuityRadius() override { int v; check(adf_wls_get_depth_discontinuity_radius(h_, &v)); return v; }
+    void setDepthDiscontinuityRadius(int v) override { check(adf_wls_set_depth_discontinuity_radius(h_, v)); }
+    Mat getConfidenceMap() override
+    {
+        Mat m;                                                                 // empty Mat before the first call (DF.cpp:153)
+        if (!use_confidence_ || last_rows_ == 0) return m;
+        mat_create(m, last_rows_, last_cols_, D32F, 1);
+        check(adf_wls_get_confidence_host(h_, 0, reinterpret_cast<float*>(m.data), mat_step(m)));
+        return m;
+    }
+    Rect getROI() override { adf_rect r; check(adf_wls_get_roi(h_, &r)); return Rect(r.x, r.y, r.width, r.height); }
+    void setSolver(int solver) override { check(adf_wls_set_solver(h_, solver)); }
+};
+
+// DF.hpp:149, DF.cpp:452-455
+inline Ptr<DisparityWLSFilter> createDisparityWLSFilterGeneric(bool use_confidence)
+{
+    return Ptr<DisparityWLSFilter>(new DisparityWLSFilterImpl(use_confidence, 0, 0, 0, 0, 0));
+}
+
+// The arithmetic of createDisparityWLSFilter (DF.cpp:392-409) on the three matcher parameters it reads.
+inline Ptr<DisparityWLSFilter> createDisparityWLSFilter(bool is_sgbm, int min_disp, int num_disp, int wsize)
+{
+    const int wsize2 = wsize / 2;
+    Ptr<DisparityWLSFilter> wls;
+    if (!is_sgbm) {                                                            // StereoBM, DF.cpp:397-403
+        wls = Ptr<DisparityWLSFilter>(new DisparityWLSFilterImpl(true, std::max(0, min_disp + num_disp) + wsize2,
+                                                                 std::max(0, -min_disp) + wsize2, wsize2, wsize2, min_disp));
+        wls->setDepthDiscontinuityRadius((int)std::ceil(0.33 * wsize));
+    } else {                                                                   // StereoSGBM, DF.cpp:404-409
+        wls = Ptr<DisparityWLSFilter>(new DisparityWLSFilterImpl(true, std::max(0, min_disp + num_disp),
+                                                                 std::max(0, -min_disp), 0, 0, min_disp));
+        wls->setDepthDiscontinuityRadius((int)std::ceil(0.5 * wsize));
+    }
+    return wls;
+}
+
+#ifdef ADF_HAVE_CALIB3D
+// DF.hpp:131, DF.cpp:386-414 (mutates the matcher exactly like the reference)
+inline Ptr<DisparityWLSFilter> createDisparityWLSFilter(cv::Ptr<cv::StereoMatcher> matcher_left)
+{
+    matcher_left->setDisp12MaxDiff(1000000);
+    matcher_left->setSpeckleWindowSize(0);
+    const int min_disp = matcher_left->getMinDisparity(), num_disp = matcher_left->getNumDisparities();
+    const int wsize = matcher_left->getBlockSize();
+    if (cv::Ptr<cv::StereoBM> bm = matcher_left.dynamicCast<cv::StereoBM>()) {
+        bm->setTextureThreshold(0);
+        bm->setUniquenessRatio(0);
+        return createDisparityWLSFilter(false, min_disp, num_disp, wsize);
+    }
+    if (cv::Ptr<cv::StereoSGBM> sgbm = matcher_left.dynamicCast<cv::StereoSGBM>()) {
+        sgbm->setUniquenessRatio(0);
+        return createDisparityWLSFilter(true, min_disp, num_disp, wsize);
+    }
+    throw Exception(ADF_EBADARG, "DisparityWLSFilter natively supports only StereoBM and StereoSGBM");
+}
+
+// DF.hpp:139, DF.cpp:417-449
+inline cv::Ptr<cv::StereoMatcher> createRightMatcher(cv::Ptr<cv::StereoMatcher> matcher_left)
+{
+    const int min_disp = matcher_left->getMinDisparity(), num_disp = matcher_left->getNumDisparities();
+    const int wsize = matcher_left->getBlockSize();
+    if (cv::Ptr<cv::StereoBM> bm = matcher_left.dynamicCast<cv::StereoBM>()) {
+        cv::Ptr<cv::StereoBM> right_bm = cv::StereoBM::create(num_disp, wsize);
+        right_bm->setMinDisparity(-(min_disp + num_disp) + 1);
+        right_bm->setTextureThreshold(0);
+        right_bm->setUniquenessRatio(0);
+        right_bm->setDisp12MaxDiff(1000000);
+        right_bm->setSpeckleWindowSize(0);
+        return right_bm;
+    }
+    if (cv::Ptr<cv::StereoSGBM> sgbm = matcher_left.dynamicCast<cv::StereoSGBM>()) {
+        cv::Ptr<cv::StereoSGBM> right_sgbm = cv::StereoSGBM::create(-(min_disp + num_disp) + 1, num_disp, wsize);
+        right_sgbm->setUniquenessRatio(0);
+        right_sgbm->setP1(sgbm->getP1());
+        right_sgbm->setP2(sgbm->getP2());
+        right_sgbm->setMode(sgbm->getMode());
+        right_sgbm->setPreFilterCap(sgbm->getPreFilterCap());
+        right_sgbm->setDisp12MaxDiff(1000000);
+        right_sgbm->setSpeckleWindowSize(0);
+        return right_sgbm;
+    }
+    throw Exception(ADF_EBADARG, "createRightMatcher supports only StereoBM and StereoSGBM");
+}
+#endif
+
+// EF.hpp:361-371
+class FastGlobalSmootherFilter {
+    adf_fgs_t* h_ = nullptr;
+    int rows_, cols_;
+public:
+    FastGlobalSmootherFilter(const Mat& guide, double lambda, double sigma_color, double lambda_attenuation, int num_iter,
+                             int solver = ADF_SOLVER_EXACT)
+        : rows_(guide.rows), cols_(guide.cols)
+    {
+        if (guide.empty() || mat_depth(guide) != D8U)                          // FGS.cpp:143-144
+            throw Exception(ADF_EBADARG, "guide must be a non-empty CV_8UC1 / CV_8UC3 image");
+        check(adf_fgs_create(&h_, guide.data, mat_step(guide), mat_channels(guide), guide.cols, guide.rows, lambda,
+                             sigma_color, lambda_attenuation, num_iter, solver));
+    }
+    ~FastGlobalSmootherFilter() { adf_fgs_destroy(h_); }
+    FastGlobalSmootherFilter(const FastGlobalSmootherFilter&) = delete;
+    FastGlobalSmootherFilter& operator=(const FastGlobalSmootherFilter&) = delete;
+    void filter(const Mat& src, Mat& dst)                                      // EF.hpp:370, FGS.cpp:182-233
+    {
+        if (src.empty()) throw Exception(ADF_EBADARG, "src is empty");
+        if (src.rows != rows_ || src.cols != cols_)                            // FGS.cpp:185-189
+            throw Exception(ADF_ESIZE, "Size of the filtered image must be equal to the size of the guide image");
+        Mat out;
+        mat_create(out, src.rows, src.cols, mat_depth(src), mat_channels(src));
+        check(adf_fgs_filter_host(h_, src.data, mat_step(src), out.data, mat_step(out), mat_depth(src), mat_channels(src)));
+        dst = out;
+    }
+};
+
+// EF.hpp:393
+inline Ptr<FastGlobalSmootherFilter> createFastGlobalSmootherFilter(const Mat& guide, double lambda, double sigma_color,
+                                                                    double lambda_attenuation = 0.25, int num_iter = 3)
+{
+    return Ptr<FastGlobalSmootherFilter>(new FastGlobalSmootherFilter(guide, lambda, sigma_color, lambda_attenuation, num_iter));
+}
+
+// EF.hpp:413
+inline void fastGlobalSmootherFilter(const Mat& guide, const Mat& src, Mat& dst, double lambda, double sigma_color,
+                                     double lambda_attenuation = 0.25, int num_iter = 3)
+{
+    createFastGlobalSmootherFilter(guide, lambda, sigma_color, lambda_attenuation, num_iter)->filter(src, dst);
+}
+
+} // namespace ximgproc
+} // namespace adf
