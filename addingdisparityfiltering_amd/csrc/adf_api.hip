@@ -111,9 +111,9 @@ struct Lut {
 };
 
 // Per-launch HIP-event timing (adf_wls_profile_*).  Events are pooled and reused.
-enum KClass { K_FILL = 0, K_WEIGHTS, K_DISC, K_LRC, K_PROLOGUE, K_PASS_H, K_PASS_V, K_PASS_V_LAST, K_COUNT };
-static const char* const kclass_names[K_COUNT] = {"fill_outside", "weights", "discontinuity", "lrc_prologue",
-                                                  "plain_prologue", "pass_h", "pass_v", "pass_v_last"};
+enum KClass { K_FILL = 0, K_WEIGHTS, K_DISC, K_LRC, K_PROLOGUE, K_PASS_H_FIRST, K_PASS_H, K_PASS_V, K_PASS_V_LAST, K_COUNT };
+static const char* const kclass_names[K_COUNT] = {"fill_outside", "weights", "discontinuity", "lrc_confidence",
+                                                  "plain_prologue", "pass_h_first", "pass_h", "pass_v", "pass_v_last"};
 struct Profiler {
     bool on = false;
     struct Rec { int cls; hipEvent_t a, b; double alg, moved; };
@@ -201,7 +201,8 @@ static int run_passes_exact(const Geom& g, const SolvePlanes& p, int n_rhs, floa
 
 // Same six passes with the on-chip partitioned solver: row-major planes, in place, algorithmic traffic.
 static int run_passes_wave(const Geom& g, const SolvePlanes& p, int n_rhs, float lambda, float atten,
-                           int num_iter, const FinalOut& fo, int n_pairs, hipStream_t st, Profiler* prof = nullptr)
+                           int num_iter, const FinalOut& fo, int n_pairs, hipStream_t st, Profiler* prof = nullptr,
+                           const WavePassArgs* fuse_first = nullptr)
 {
     float lam = lambda;
     const double px = (double)g.rw * g.rh * n_pairs;
@@ -210,8 +211,16 @@ static int run_passes_wave(const Geom& g, const SolvePlanes& p, int n_rhs, float
         WavePassArgs h{};
         h.C = p.CH; h.U0 = p.A0; h.U1 = p.A1;
         h.nscan = g.rh; h.len = g.rw; h.pitch = g.pw; h.plane = g.plane; h.lambda = lam;
+        const bool fused = (it == 0 && fuse_first);
+        if (fused) {   // U1 = conf, U0 = conf*float(dL) formed in the pass (DF.cpp:288-290)
+            h.conf_in = fuse_first->conf_in; h.conf_frame = fuse_first->conf_frame; h.conf_pitch = fuse_first->conf_pitch;
+            h.conf_x0 = fuse_first->conf_x0; h.conf_y0 = fuse_first->conf_y0;
+            h.dl_in = fuse_first->dl_in; h.dl_stride = fuse_first->dl_stride; h.dl_pair_stride = fuse_first->dl_pair_stride;
+            h.dl_x0 = fuse_first->dl_x0; h.dl_y0 = fuse_first->dl_y0;
+        }
         {
-            ProfScope ps(prof, K_PASS_H, alg, alg, st);
+            const double b = fused ? (4.0 + 4.0 + 2.0 + 8.0) * px : alg;  // C + conf + dL read, U0/U1 written
+            ProfScope ps(prof, fused ? K_PASS_H_FIRST : K_PASS_H, b, b, st);
             HIP_TRY(launch_wave_hpass(h, n_rhs, n_pairs, st));             // FGS.cpp:209
         }
         const bool last = (it == num_iter - 1);
@@ -446,23 +455,53 @@ extern "C" int adf_wls_filter_device(adf_wls_t* h, int n_pairs,
         if (conf) {
             const int16_t* dRp = (const int16_t*)((const char*)dispR + (ptrdiff_t)first * psR);
             const int rrx = W - (roi.x + roi.width);                       // DF.cpp:202
+            float* confp = (float*)h->conf.p + (size_t)first * g.frame;
+            const int thresh = (int)(1.0f * h->lrc_thresh);                // DF.cpp:318 (resize_factor 1)
             DiscArgs da{};
             da.disp[0] = dL; da.stride[0] = sL; da.pair_stride[0] = psL; da.rx[0] = roi.x; da.dst[0] = cL;
             da.disp[1] = dRp; da.stride[1] = sR; da.pair_stride[1] = psR; da.rx[1] = rrx; da.dst[1] = cR;
             da.ry = roi.y; da.rw = roi.width; da.rh = roi.height; da.radius = h->disc_radius;
-            da.roll_off = h->roll_off; da.W = W; da.frame = g.frame;
-            {   // reads the int16 ROIs, writes the float maps (the maps themselves are not algorithmic I/O)
-                ProfScope ps(prof, K_DISC, 4.0 * P, 12.0 * P, st);
-                HIP_TRY(launch_discontinuity(da, n, st));                  // DF.cpp:204
-            }
-            LrcArgs la{dL, sL, psL, dRp, sR, psR, cL, cR, (float*)h->conf.p + (size_t)first * g.frame,
-                       o, sO, psO, fill, p.A0, p.A1, g, rrx, (int)(1.0f * h->lrc_thresh) /* DF.cpp:318 */, orient_h};
-            {   // alg: confidence map out (4F) + the two rhs planes (8P); moved adds dL,dR,cL,cR reads
-                ProfScope ps(prof, K_LRC, 4.0 * F + 8.0 * P + 2.0 * (F - P), 4.0 * F + 20.0 * P + 2.0 * (F - P), st);
-                HIP_TRY(launch_lrc_prologue(la, n, st));                   // DF.cpp:208-209,288-290
+            da.roll_off = h->roll_off; da.W = W; da.frame = g.frame; da.only_view = -1;
+            WavePassArgs fuse{};                                            // inputs of a fused first pass
+            if (wave && h->disc_radius <= conf_left_max_radius()) {
+                // wave path: right map, then left map + LRC + x255 in one sweep (cL never hits memory);
+                // the first horizontal pass forms conf*disp itself when alignment allows
+                da.only_view = 1;
+                {
+                    ProfScope ps(prof, K_DISC, 2.0 * P, 6.0 * P, st);
+                    HIP_TRY(launch_discontinuity(da, n, st));              // DF.cpp:204 (right view)
+                }
+                fuse.conf_in = confp; fuse.conf_frame = g.frame; fuse.conf_pitch = W; fuse.conf_x0 = roi.x; fuse.conf_y0 = roi.y;
+                fuse.dl_in = dL; fuse.dl_stride = sL; fuse.dl_pair_stride = psL; fuse.dl_x0 = roi.x; fuse.dl_y0 = roi.y;
+                fuse.len = g.rw;
+                const bool fused_h = wave_hpass_can_fuse(fuse);
+                if (!fused_h) fuse = WavePassArgs{};
+                ConfLeftArgs ca{dL, sL, psL, dRp, sR, psR, cR, confp, fused_h ? nullptr : p.A0, fused_h ? nullptr : p.A1,
+                                g, rrx, thresh, h->disc_radius, h->roll_off};
+                {   // alg: conf (4P); moved: dL 2 + dR 2 + cR 4 reads, conf 4 (+8 when U0/U1 are materialised)
+                    const double wu = fused_h ? 0.0 : 8.0;
+                    ProfScope ps(prof, K_LRC, (4.0 + wu) * P, (12.0 + wu) * P, st);
+                    HIP_TRY(launch_conf_left(ca, n, st));                  // DF.cpp:204-209 (+288-290)
+                }
+                OutsideArgs oa{o, sO, psO, fill, confp, g};
+                {
+                    ProfScope ps(prof, K_FILL, 6.0 * (F - P), 6.0 * (F - P), st);
+                    HIP_TRY(launch_outside(oa, n, st));                    // DF.cpp:284, :187-190
+                }
+            } else {
+                {   // reads the int16 ROIs, writes the float maps (the maps themselves are not algorithmic I/O)
+                    ProfScope ps(prof, K_DISC, 4.0 * P, 12.0 * P, st);
+                    HIP_TRY(launch_discontinuity(da, n, st));              // DF.cpp:204
+                }
+                LrcArgs la{dL, sL, psL, dRp, sR, psR, cL, cR, confp, o, sO, psO, fill, p.A0, p.A1, g, rrx, thresh, orient_h};
+                {   // alg: confidence map out (4F) + the two rhs planes (8P); moved adds dL,dR,cL,cR reads
+                    ProfScope ps(prof, K_LRC, 4.0 * F + 8.0 * P + 2.0 * (F - P), 4.0 * F + 20.0 * P + 2.0 * (F - P), st);
+                    HIP_TRY(launch_lrc_prologue(la, n, st));               // DF.cpp:208-209,288-290
+                }
             }
             FinalOut fo{EPI_WLS_CONF, o, sO, psO, roi.x, roi.y, 1, 0};
-            rc = wave ? run_passes_wave(g, p, 2, (float)h->lambda, (float)h->atten, h->num_iter, fo, n, st, prof)
+            rc = wave ? run_passes_wave(g, p, 2, (float)h->lambda, (float)h->atten, h->num_iter, fo, n, st, prof,
+                                        fuse.conf_in ? &fuse : nullptr)
                       : run_passes_exact(g, p, 2, (float)h->lambda, (float)h->atten, h->num_iter, fo, n, st, prof);
             if (rc) return rc;                                             // DF.cpp:292-296
         } else {

@@ -41,6 +41,26 @@ struct DiscArgs {
     int rx[2]; int ry, rw, rh;
     int radius; float roll_off;
     float* dst[2]; int W; size_t frame; // full-frame float planes, W pitch
+    int only_view;                      // -1 = both views, else the one view to compute
+};
+
+// Left view: discontinuity map + LRC + x255 in one sweep (no cL round trip through HBM); needs the
+// right view's discontinuity map cR complete.  Optionally also writes the two right-hand sides.
+struct ConfLeftArgs {
+    const int16_t* dL; ptrdiff_t sL, psL; // bytes
+    const int16_t* dR; ptrdiff_t sR, psR;
+    const float* cR;                      // full-frame, W pitch
+    float* conf;                          // full-frame confidence (x255); only ROI pixels are written
+    float* U0; float* U1;                 // row-major ROI planes (may be null: first pass reads conf/dL itself)
+    Geom g; int rrx; int thresh;
+    int radius; float roll_off;
+};
+
+// Non-ROI pixels: filtered map = fill (DF.cpp:284), confidence = 0 (DF.cpp:187-190); either may be null.
+struct OutsideArgs {
+    int16_t* out; ptrdiff_t stride, pair_stride; int16_t fill;
+    float* conf;
+    Geom g;
 };
 
 struct LrcArgs {
@@ -92,6 +112,10 @@ struct PassArgs {
 // len = column length.  The last vertical pass may fuse an epilogue and write `out` instead.
 struct WavePassArgs {
     const float* C; float* U0; float* U1;
+    // fused prologue of the first horizontal pass (DF.cpp:288-290): when conf_in is set the right-hand
+    // sides are read as U1 = conf, U0 = conf * float(dL) from the confidence plane and the disparity map
+    const float* conf_in; size_t conf_frame; int conf_pitch, conf_x0, conf_y0;
+    const int16_t* dl_in; ptrdiff_t dl_stride, dl_pair_stride; int dl_x0, dl_y0;
     void* out; ptrdiff_t out_stride, out_pair_stride;
     int out_x0, out_y0, out_cn, out_c;
     int nscan, len, pitch;
@@ -102,6 +126,9 @@ struct WavePassArgs {
 // Launchers (defined in the .hip files).  All are asynchronous on `st`.
 hipError_t launch_discontinuity(const DiscArgs& a, int n_pairs, hipStream_t st);
 hipError_t launch_lrc_prologue(const LrcArgs& a, int n_pairs, hipStream_t st);
+hipError_t launch_conf_left(const ConfLeftArgs& a, int n_pairs, hipStream_t st); // radius <= 8 only
+hipError_t launch_outside(const OutsideArgs& a, int n_pairs, hipStream_t st);
+int conf_left_max_radius();
 hipError_t launch_plain_prologue(const PlainPrologueArgs& a, int n_pairs, hipStream_t st);
 hipError_t launch_weights(const WeightArgs& a, int n_pairs, hipStream_t st);
 hipError_t launch_fill_outside(const FillArgs& a, int n_pairs, hipStream_t st);
@@ -109,6 +136,7 @@ hipError_t launch_exact_pass(const PassArgs& a, int n_rhs, int epilogue, int n_p
 hipError_t launch_wave_hpass(const WavePassArgs& a, int n_rhs, int n_pairs, hipStream_t st);
 hipError_t launch_wave_vpass(const WavePassArgs& a, int n_rhs, int epilogue, int n_pairs, hipStream_t st);
 int wave_max_row_len();
+bool wave_hpass_can_fuse(const WavePassArgs& a);
 int wave_max_col_len();
 // largest depth-discontinuity radius the tile kernel supports (LDS bound)
 int max_disc_radius();

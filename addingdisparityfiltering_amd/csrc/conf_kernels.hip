@@ -43,8 +43,8 @@ __global__ void __launch_bounds__(NT) discontinuity_kernel(DiscArgs a)
 
     const int tid = threadIdx.x, tx = tid & (TX - 1), ty = tid / TX;
     const int x0 = blockIdx.x * TX, y0 = blockIdx.y * TY;
-    const int view = blockIdx.z & 1;
-    const size_t pz = blockIdx.z >> 1;
+    const int view = a.only_view >= 0 ? a.only_view : (int)(blockIdx.z & 1);
+    const size_t pz = a.only_view >= 0 ? blockIdx.z : (blockIdx.z >> 1);
     const char* base = reinterpret_cast<const char*>(a.disp[view]) + (ptrdiff_t)pz * a.pair_stride[view];
     const int rx = a.rx[view];
 
@@ -117,8 +117,8 @@ __global__ void __launch_bounds__(NT) discontinuity_col_kernel(DiscArgs a)
     constexpr int OUTW = NT - 2 * RT;
     __shared__ int rowbuf[2][NT];
     const int tid = threadIdx.x;
-    const int view = blockIdx.z & 1;
-    const size_t pz = blockIdx.z >> 1;
+    const int view = a.only_view >= 0 ? a.only_view : (int)(blockIdx.z & 1);
+    const size_t pz = a.only_view >= 0 ? blockIdx.z : (blockIdx.z >> 1);
     const int x_out0 = blockIdx.x * OUTW, y_out0 = blockIdx.y * DC_ROWS;
     const char* base = reinterpret_cast<const char*>(a.disp[view]) + (ptrdiff_t)pz * a.pair_stride[view];
     const int rx = a.rx[view];
@@ -177,6 +177,112 @@ __global__ void __launch_bounds__(NT) discontinuity_col_kernel(DiscArgs a)
             }
         }
     }
+}
+
+// ---------------------------------------------------------------------------------------
+// Left view, fused: the column-walking discontinuity sweep above, and for every completed window the
+// left-right check against the (already finished) right map, x255, and the confidence map written
+// straight away -- the left discontinuity map never exists in memory (DF.cpp:204-209 in one pass).
+// With WRITE_U the right-hand sides conf*float(dL), conf (DF.cpp:288-290) are written as well.
+// ---------------------------------------------------------------------------------------
+template <int RT, bool WRITE_U>
+__global__ void __launch_bounds__(NT) conf_left_kernel(ConfLeftArgs a)
+{
+    constexpr int K = 2 * RT + 1;
+    constexpr int OUTW = NT - 2 * RT;
+    constexpr int U = K * ((16 + K - 1) / K);
+    __shared__ int rowbuf[2][NT];
+    const Geom& g = a.g;
+    const int tid = threadIdx.x;
+    const size_t pz = blockIdx.z;
+    const int x_out0 = blockIdx.x * OUTW, y_out0 = blockIdx.y * DC_ROWS;
+    const char* baseL = reinterpret_cast<const char*>(a.dL) + (ptrdiff_t)pz * a.psL;
+    const char* baseR = reinterpret_cast<const char*>(a.dR) + (ptrdiff_t)pz * a.psR;
+    const float* cR = a.cR + pz * g.frame;
+    float* conf = a.conf + pz * g.frame;
+    const int gx_in = reflect101(x_out0 - RT + tid, g.rw);
+    const int gx_out = x_out0 + tid - RT;
+    const bool writer = tid >= RT && tid < NT - RT && gx_out < g.rw;
+    const int j_abs = g.rx + gx_out;                              // frame column of this thread's output
+    const int nrows = min(DC_ROWS, g.rh - y_out0) + 2 * RT;
+    const double scale = 1.0 / ((double)K * (double)K);
+    const int right_end = a.rrx + g.rw;
+
+    auto load = [&](int n) -> int {
+        const int gy = reflect101(y_out0 - RT + n, g.rh);
+        return reinterpret_cast<const int16_t*>(baseL + (ptrdiff_t)(g.ry + gy) * a.sL)[g.rx + gx_in];
+    };
+
+    int r1[K], rlo[K], rhi[K], raw[K];
+    int S1 = 0, Slo = 0, Shi = 0;
+    int nxt[U];
+#pragma unroll
+    for (int s = 0; s < U; s++) nxt[s] = (s < nrows) ? load(s) : 0;
+    for (int n0 = 0; n0 < nrows; n0 += U) {
+        int cur[U];
+#pragma unroll
+        for (int s = 0; s < U; s++) { cur[s] = nxt[s]; nxt[s] = (n0 + U + s < nrows) ? load(n0 + U + s) : 0; }
+#pragma unroll
+        for (int s = 0; s < U; s++) {
+            const int n = n0 + s;
+            const int slot = s % K;
+            const int cslot = (s + K - RT) % K;                   // slot of the window's centre row n-RT
+            if (n < nrows) {
+                rowbuf[n & 1][tid] = cur[s];
+                __syncthreads();
+                int h1 = 0, hlo = 0, hhi = 0;
+                if (tid >= RT && tid < NT - RT) {
+#pragma unroll
+                    for (int d = -RT; d <= RT; d++) {
+                        const int v = rowbuf[n & 1][tid + d];
+                        const int q = v * v;
+                        h1 += v; hlo += q & 0xffff; hhi += q >> 16;
+                    }
+                }
+                if (n >= K) { S1 -= r1[slot]; Slo -= rlo[slot]; Shi -= rhi[slot]; }
+                r1[slot] = h1; rlo[slot] = hlo; rhi[slot] = hhi; raw[slot] = cur[s];
+                S1 += h1; Slo += hlo; Shi += hhi;
+                if (n >= 2 * RT && writer) {
+                    const int oy = y_out0 + n - 2 * RT;           // ROI row; the centre row is never a reflected one
+                    const int i_abs = g.ry + oy;
+                    const float mean = (float)((double)S1 * scale);
+                    const float sq = (float)(((double)Shi * 65536.0 + (double)Slo) * scale);
+                    const float variance = sq - mean * mean;      // DF.cpp:369
+                    float c = 1.0f - a.roll_off * variance;       // DF.cpp:370
+                    c = c < 0.0f ? 0.0f : c;
+                    const int d = raw[cslot];
+                    const int ridx = j_abs - (d >> 4);            // DF.cpp:331
+                    if (ridx >= a.rrx && ridx < right_end) {
+                        const int dr = reinterpret_cast<const int16_t*>(baseR + (ptrdiff_t)i_abs * a.sR)[ridx];
+                        if (abs(d + dr) < a.thresh) {             // DF.cpp:334
+                            const float b = cR[(size_t)i_abs * g.W + ridx];
+                            c = b < c ? b : c;                    // DF.cpp:335
+                        } else
+                            c = 0.0f;                             // DF.cpp:337
+                    }
+                    c = 255.0f * c;                               // DF.cpp:209
+                    conf[(size_t)i_abs * g.W + j_abs] = c;
+                    if (WRITE_U) {
+                        const size_t o = pz * g.plane + (size_t)oy * g.pw + gx_out;
+                        a.U0[o] = c * (float)d;                   // DF.cpp:289-290
+                        a.U1[o] = c;
+                    }
+                }
+            }
+        }
+    }
+}
+
+__global__ void __launch_bounds__(NT) outside_kernel(OutsideArgs a)
+{
+    const Geom& g = a.g;
+    const int j = blockIdx.x * NT + threadIdx.x, i = blockIdx.y;
+    if (j >= g.W) return;
+    if (j >= g.rx && j < g.rx + g.rw && i >= g.ry && i < g.ry + g.rh) return;
+    if (a.out)
+        reinterpret_cast<int16_t*>(reinterpret_cast<char*>(a.out) + (ptrdiff_t)blockIdx.z * a.pair_stride +
+                                   (ptrdiff_t)i * a.stride)[j] = a.fill;
+    if (a.conf) a.conf[(size_t)blockIdx.z * g.frame + (size_t)i * g.W + j] = 0.0f;
 }
 
 // ---------------------------------------------------------------------------------------
@@ -320,7 +426,7 @@ hipError_t launch_discontinuity(const DiscArgs& a, int n_pairs, hipStream_t st)
     if (a.rw <= 0 || a.rh <= 0 || n_pairs <= 0) return hipSuccess;
     if (a.radius < 0 || a.radius > MAX_RADIUS) return hipErrorInvalidValue;
     if (a.radius <= 8) {
-        dim3 grid(1, (a.rh + DC_ROWS - 1) / DC_ROWS, 2 * n_pairs);
+        dim3 grid(1, (a.rh + DC_ROWS - 1) / DC_ROWS, (a.only_view >= 0 ? 1 : 2) * n_pairs);
 #define ADF_DC(RR)                                                                             \
     case RR:                                                                                   \
         grid.x = (a.rw + (NT - 2 * RR) - 1) / (NT - 2 * RR);                                   \
@@ -341,8 +447,33 @@ hipError_t launch_discontinuity(const DiscArgs& a, int n_pairs, hipStream_t st)
         if (e != hipSuccess) return e;
         configured = lds;
     }
-    dim3 grid((a.rw + TX - 1) / TX, (a.rh + TY - 1) / TY, 2 * n_pairs);
+    dim3 grid((a.rw + TX - 1) / TX, (a.rh + TY - 1) / TY, (a.only_view >= 0 ? 1 : 2) * n_pairs);
     hipLaunchKernelGGL(discontinuity_kernel, grid, dim3(NT), lds, st, a);
+    return hipGetLastError();
+}
+
+int conf_left_max_radius() { return 8; }
+
+hipError_t launch_conf_left(const ConfLeftArgs& a, int n_pairs, hipStream_t st)
+{
+    if (a.radius < 0 || a.radius > 8) return hipErrorInvalidValue;
+    const bool wu = a.U0 != nullptr;
+    dim3 grid(1, (a.g.rh + DC_ROWS - 1) / DC_ROWS, n_pairs);
+#define ADF_CL(RR)                                                                             \
+    case RR:                                                                                   \
+        grid.x = (a.g.rw + (NT - 2 * RR) - 1) / (NT - 2 * RR);                                 \
+        if (wu) hipLaunchKernelGGL((conf_left_kernel<RR, true>), grid, dim3(NT), 0, st, a);    \
+        else hipLaunchKernelGGL((conf_left_kernel<RR, false>), grid, dim3(NT), 0, st, a);      \
+        break;
+    switch (a.radius) { ADF_CL(0) ADF_CL(1) ADF_CL(2) ADF_CL(3) ADF_CL(4) ADF_CL(5) ADF_CL(6) ADF_CL(7) ADF_CL(8) }
+#undef ADF_CL
+    return hipGetLastError();
+}
+
+hipError_t launch_outside(const OutsideArgs& a, int n_pairs, hipStream_t st)
+{
+    dim3 grid((a.g.W + NT - 1) / NT, a.g.H, n_pairs);
+    hipLaunchKernelGGL(outside_kernel, grid, dim3(NT), 0, st, a);
     return hipGetLastError();
 }
 

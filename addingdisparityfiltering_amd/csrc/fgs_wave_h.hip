@@ -9,7 +9,10 @@ using namespace wave;
 // ---------------------------------------------------------------------------------------------
 // Horizontal pass: one wavefront per row, in place.
 // ---------------------------------------------------------------------------------------------
-template <int M, int R>
+// FUSED: first pass of a confidence-mode call -- the right-hand sides are formed on the fly from the
+// confidence plane and the left disparity map (U1 = conf, U0 = conf*float(dL), DF.cpp:288-290) instead
+// of being read from planes a prologue kernel would have had to write.
+template <int M, int R, bool FUSED>
 __global__ void __launch_bounds__(64, 2) wave_hpass_kernel(WavePassArgs a)
 {
     static_assert(M % 4 == 0 && M >= 4, "chunk length must be a multiple of 4");
@@ -27,13 +30,30 @@ __global__ void __launch_bounds__(64, 2) wave_hpass_kernel(WavePassArgs a)
         const float4* sC = reinterpret_cast<const float4*>(a.C + off);
         const float4* s0 = reinterpret_cast<const float4*>(a.U0 + off);
         const float4* s1 = (R > 1) ? reinterpret_cast<const float4*>(a.U1 + off) : nullptr;
+        // fused inputs (the launcher guarantees 16 / 8 byte alignment and len % 4 == 0)
+        const float4* sF = nullptr; const short4* sD = nullptr;
+        if (FUSED) {
+            sF = reinterpret_cast<const float4*>(a.conf_in + (size_t)blockIdx.y * a.conf_frame +
+                                                 (size_t)(a.conf_y0 + blockIdx.x) * a.conf_pitch + a.conf_x0);
+            sD = reinterpret_cast<const short4*>(reinterpret_cast<const char*>(a.dl_in) + (ptrdiff_t)blockIdx.y * a.dl_pair_stride +
+                                                 (ptrdiff_t)(a.dl_y0 + blockIdx.x) * a.dl_stride + (ptrdiff_t)a.dl_x0 * 2);
+        }
+        const int nfused = a.len >> 2;
         // (an explicit branch per load: "cond ? *p : zero" would make the compiler select between
         // addresses and park the zero in scratch memory)
 #pragma unroll
         for (int k = 0; k < M / 4; k++) {
             const int idx = 64 * k + lane;
             tC[k] = make_float4(0.f, 0.f, 0.f, 0.f); t0[k] = tC[k]; t1[k] = tC[k];
-            if (idx < nvec) {
+            if (FUSED) {
+                if (idx < nvec) tC[k] = sC[idx];
+                if (idx < nfused) {
+                    const float4 cf = sF[idx];
+                    const short4 dd = sD[idx];
+                    t1[k] = cf;
+                    t0[k] = make_float4(cf.x * (float)dd.x, cf.y * (float)dd.y, cf.z * (float)dd.z, cf.w * (float)dd.w);
+                }
+            } else if (idx < nvec) {
                 tC[k] = sC[idx];
                 t0[k] = s0[idx];
                 if (R > 1) t1[k] = s1[idx];
@@ -99,8 +119,11 @@ template <int M>
 hipError_t launch_h(const WavePassArgs& a, int n_rhs, int n_pairs, hipStream_t st)
 {
     dim3 grid(a.nscan, n_pairs), block(64);
-    if (n_rhs == 2) hipLaunchKernelGGL((wave_hpass_kernel<M, 2>), grid, block, 0, st, a);
-    else hipLaunchKernelGGL((wave_hpass_kernel<M, 1>), grid, block, 0, st, a);
+    if (a.conf_in) {
+        if (n_rhs != 2) return hipErrorInvalidValue;
+        hipLaunchKernelGGL((wave_hpass_kernel<M, 2, true>), grid, block, 0, st, a);
+    } else if (n_rhs == 2) hipLaunchKernelGGL((wave_hpass_kernel<M, 2, false>), grid, block, 0, st, a);
+    else hipLaunchKernelGGL((wave_hpass_kernel<M, 1, false>), grid, block, 0, st, a);
     return hipGetLastError();
 }
 
@@ -108,9 +131,22 @@ hipError_t launch_h(const WavePassArgs& a, int n_rhs, int n_pairs, hipStream_t s
 
 int wave_max_row_len() { return 64 * 64; }
 
+// The fused first pass reads conf as float4 and dL as short4: everything must be 16 / 8 byte aligned
+// and the row length a multiple of 4 (otherwise the caller materialises U0/U1 with the prologue).
+bool wave_hpass_can_fuse(const WavePassArgs& a)
+{
+    if (!a.conf_in || !a.dl_in) return false;
+    if (a.len % 4 != 0 || a.conf_pitch % 4 != 0 || a.conf_x0 % 4 != 0 || a.conf_frame % 4 != 0) return false;
+    if ((reinterpret_cast<uintptr_t>(a.conf_in) & 15u) != 0) return false;
+    if (a.dl_x0 % 4 != 0 || a.dl_stride % 8 != 0 || a.dl_pair_stride % 8 != 0) return false;
+    if ((reinterpret_cast<uintptr_t>(a.dl_in) & 7u) != 0) return false;
+    return true;
+}
+
 hipError_t launch_wave_hpass(const WavePassArgs& a, int n_rhs, int n_pairs, hipStream_t st)
 {
     if (a.len < 2 || a.len > wave_max_row_len() || a.pitch % 64 != 0 || a.pitch < a.len) return hipErrorInvalidValue;
+    if (a.conf_in && !wave_hpass_can_fuse(a)) return hipErrorInvalidValue;
     const int m = (a.len + 63) / 64;
     if (m <= 4) return launch_h<4>(a, n_rhs, n_pairs, st);
     if (m <= 8) return launch_h<8>(a, n_rhs, n_pairs, st);
