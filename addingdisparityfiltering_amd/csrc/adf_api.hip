@@ -442,9 +442,9 @@ extern "C" int adf_wls_filter_device(adf_wls_t* h, int n_pairs,
         Profiler* prof = &h->prof;
         const int16_t fill = (int16_t)(16 * (h->min_disp - 1));            // DF.cpp:254,284
         if (!conf) {                                                       // with confidence the LRC kernel fills
-            FillArgs fa{o, sO, psO, g, fill};
+            OutsideArgs oa{o, sO, psO, fill, nullptr, g};
             ProfScope ps(prof, K_FILL, 2.0 * (F - P), 2.0 * (F - P), st);
-            HIP_TRY(launch_fill_outside(fa, n, st));
+            HIP_TRY(launch_outside(oa, n, st));
         }
         WeightArgs wa{gv, sG, psG, gch, (const float*)h->lut.dev.p, p.CH, p.CV, orient_h, ORIENT_N, g};
         {

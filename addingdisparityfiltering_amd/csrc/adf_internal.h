@@ -89,11 +89,6 @@ struct WeightArgs {
     Geom g;
 };
 
-struct FillArgs {
-    int16_t* out; ptrdiff_t stride, pair_stride; // bytes
-    Geom g; int16_t value;
-};
-
 // One solve pass (forward elimination + back substitution along every scanline).
 // Input planes have the scanline index fastest: element (step t, scanline s) at t*pitch_in + s.
 struct PassArgs {
@@ -131,7 +126,6 @@ hipError_t launch_outside(const OutsideArgs& a, int n_pairs, hipStream_t st);
 int conf_left_max_radius();
 hipError_t launch_plain_prologue(const PlainPrologueArgs& a, int n_pairs, hipStream_t st);
 hipError_t launch_weights(const WeightArgs& a, int n_pairs, hipStream_t st);
-hipError_t launch_fill_outside(const FillArgs& a, int n_pairs, hipStream_t st);
 hipError_t launch_exact_pass(const PassArgs& a, int n_rhs, int epilogue, int n_pairs, hipStream_t st);
 hipError_t launch_wave_hpass(const WavePassArgs& a, int n_rhs, int n_pairs, hipStream_t st);
 hipError_t launch_wave_vpass(const WavePassArgs& a, int n_rhs, int epilogue, int n_pairs, hipStream_t st);

@@ -8,7 +8,8 @@
 //                          pass wants
 //   plain_prologue_kernel: source channel -> float right-hand side: the no-confidence path's
 //                          float(disp) (DF.cpp:250,257) and FGS.cpp:191-205 (split + convertTo)
-//   fill_outside_kernel  : out = 16*(min_disp-1) = -16 outside the ROI (DF.cpp:149,254,284)
+//   outside_kernel       : out = 16*(min_disp-1) = -16 and confidence 0 outside the ROI
+//                          (DF.cpp:149,254,284; :187-190)
 //
 // All of this is integer / elementwise float work: HBM-bound, no MFMA.  Arithmetic that must
 // match the CPU restatement bit for bit is written as separate roundings (contraction off).
@@ -110,6 +111,14 @@ __global__ void __launch_bounds__(NT) discontinuity_kernel(DiscArgs a)
 // ---------------------------------------------------------------------------------------
 constexpr int DC_ROWS = 128; // output rows per block
 
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains every outstanding
+// global load (s_waitcnt vmcnt(0)), which would serialise the row prefetch and the LRC gathers of the
+// column-walking kernels behind each row's barrier.
+__device__ __forceinline__ void lds_barrier()
+{
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
 template <int RT>
 __global__ void __launch_bounds__(NT) discontinuity_col_kernel(DiscArgs a)
 {
@@ -153,7 +162,7 @@ __global__ void __launch_bounds__(NT) discontinuity_col_kernel(DiscArgs a)
             const int slot = s % K;                               // compile-time after unrolling
             if (n < nrows) {                                     // block-uniform
                 rowbuf[n & 1][tid] = cur[s];
-                __syncthreads();
+                lds_barrier();
                 int h1 = 0, hlo = 0, hhi = 0;
                 if (tid >= RT && tid < NT - RT) {
 #pragma unroll
@@ -229,7 +238,7 @@ __global__ void __launch_bounds__(NT) conf_left_kernel(ConfLeftArgs a)
             const int cslot = (s + K - RT) % K;                   // slot of the window's centre row n-RT
             if (n < nrows) {
                 rowbuf[n & 1][tid] = cur[s];
-                __syncthreads();
+                lds_barrier();
                 int h1 = 0, hlo = 0, hhi = 0;
                 if (tid >= RT && tid < NT - RT) {
 #pragma unroll
@@ -273,16 +282,28 @@ __global__ void __launch_bounds__(NT) conf_left_kernel(ConfLeftArgs a)
     }
 }
 
+constexpr int OUT_ROWS = 16; // rows per block of outside_kernel
+
 __global__ void __launch_bounds__(NT) outside_kernel(OutsideArgs a)
 {
+    // blockIdx.x walks the columns that can be outside the ROI: all W columns when some row lies
+    // outside the ROI's row range, else only the W - rw columns left and right of it
     const Geom& g = a.g;
-    const int j = blockIdx.x * NT + threadIdx.x, i = blockIdx.y;
-    if (j >= g.W) return;
-    if (j >= g.rx && j < g.rx + g.rw && i >= g.ry && i < g.ry + g.rh) return;
-    if (a.out)
-        reinterpret_cast<int16_t*>(reinterpret_cast<char*>(a.out) + (ptrdiff_t)blockIdx.z * a.pair_stride +
-                                   (ptrdiff_t)i * a.stride)[j] = a.fill;
-    if (a.conf) a.conf[(size_t)blockIdx.z * g.frame + (size_t)i * g.W + j] = 0.0f;
+    const bool full_rows = g.ry > 0 || g.ry + g.rh < g.H;
+    const int t = blockIdx.x * NT + threadIdx.x;
+    for (int k = 0; k < OUT_ROWS; k++) {
+        const int i = blockIdx.y * OUT_ROWS + k;
+        if (i >= g.H) break;
+        const bool roi_row = i >= g.ry && i < g.ry + g.rh;
+        int j;
+        if (full_rows && !roi_row) j = t;
+        else { if (t >= g.W - g.rw) continue; j = t < g.rx ? t : t + g.rw; }
+        if (j >= g.W) continue;
+        if (a.out)
+            reinterpret_cast<int16_t*>(reinterpret_cast<char*>(a.out) + (ptrdiff_t)blockIdx.z * a.pair_stride +
+                                       (ptrdiff_t)i * a.stride)[j] = a.fill;
+        if (a.conf) a.conf[(size_t)blockIdx.z * g.frame + (size_t)i * g.W + j] = 0.0f;
+    }
 }
 
 // ---------------------------------------------------------------------------------------
@@ -399,18 +420,6 @@ __global__ void __launch_bounds__(NT) plain_prologue_kernel(PlainPrologueArgs a)
     }
 }
 
-__global__ void __launch_bounds__(NT) fill_outside_kernel(FillArgs a)
-{
-    const Geom& g = a.g;
-    const int j = blockIdx.x * NT + threadIdx.x, i = blockIdx.y;
-    if (j >= g.W) return;
-    const bool in_roi = j >= g.rx && j < g.rx + g.rw && i >= g.ry && i < g.ry + g.rh;
-    if (in_roi) return;
-    int16_t* row = reinterpret_cast<int16_t*>(reinterpret_cast<char*>(a.out) +
-                                              (ptrdiff_t)blockIdx.z * a.pair_stride + (ptrdiff_t)i * a.stride);
-    row[j] = a.value;
-}
-
 inline size_t disc_lds_bytes(int r)
 {
     const size_t IH = TY + 2 * r, IWP = (TX + 2 * r) | 1;
@@ -472,7 +481,10 @@ hipError_t launch_conf_left(const ConfLeftArgs& a, int n_pairs, hipStream_t st)
 
 hipError_t launch_outside(const OutsideArgs& a, int n_pairs, hipStream_t st)
 {
-    dim3 grid((a.g.W + NT - 1) / NT, a.g.H, n_pairs);
+    const bool full_rows = a.g.ry > 0 || a.g.ry + a.g.rh < a.g.H;
+    const int cols = full_rows ? a.g.W : a.g.W - a.g.rw;
+    if (cols <= 0) return hipSuccess;
+    dim3 grid((cols + NT - 1) / NT, (a.g.H + OUT_ROWS - 1) / OUT_ROWS, n_pairs);
     hipLaunchKernelGGL(outside_kernel, grid, dim3(NT), 0, st, a);
     return hipGetLastError();
 }
@@ -488,13 +500,6 @@ hipError_t launch_plain_prologue(const PlainPrologueArgs& a, int n_pairs, hipStr
 {
     dim3 grid((a.g.rw + TX - 1) / TX, (a.g.rh + TY - 1) / TY, n_pairs);
     hipLaunchKernelGGL(plain_prologue_kernel, grid, dim3(NT), 0, st, a);
-    return hipGetLastError();
-}
-
-hipError_t launch_fill_outside(const FillArgs& a, int n_pairs, hipStream_t st)
-{
-    dim3 grid((a.g.W + NT - 1) / NT, a.g.H, n_pairs);
-    hipLaunchKernelGGL(fill_outside_kernel, grid, dim3(NT), 0, st, a);
     return hipGetLastError();
 }
 
