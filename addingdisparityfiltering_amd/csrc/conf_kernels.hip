@@ -200,6 +200,7 @@ __global__ void __launch_bounds__(NT) conf_left_kernel(ConfLeftArgs a)
     constexpr int K = 2 * RT + 1;
     constexpr int OUTW = NT - 2 * RT;
     constexpr int U = K * ((16 + K - 1) / K);
+    constexpr int CR = RT > 0 ? RT : 1;
     __shared__ int rowbuf[2][NT];
     const Geom& g = a.g;
     const int tid = threadIdx.x;
@@ -210,10 +211,11 @@ __global__ void __launch_bounds__(NT) conf_left_kernel(ConfLeftArgs a)
     const float* cR = a.cR + pz * g.frame;
     float* conf = a.conf + pz * g.frame;
     const int gx_in = reflect101(x_out0 - RT + tid, g.rw);
-    const int gx_out = x_out0 + tid - RT;
+    const int gx_out = x_out0 + tid - RT;                          // == gx_in for writer threads
     const bool writer = tid >= RT && tid < NT - RT && gx_out < g.rw;
     const int j_abs = g.rx + gx_out;                              // frame column of this thread's output
-    const int nrows = min(DC_ROWS, g.rh - y_out0) + 2 * RT;
+    const int rows_out = min(DC_ROWS, g.rh - y_out0);
+    const int nrows = rows_out + 2 * RT;                          // input rows this block consumes
     const double scale = 1.0 / ((double)K * (double)K);
     const int right_end = a.rrx + g.rw;
 
@@ -222,21 +224,42 @@ __global__ void __launch_bounds__(NT) conf_left_kernel(ConfLeftArgs a)
         return reinterpret_cast<const int16_t*>(baseL + (ptrdiff_t)(g.ry + gy) * a.sL)[g.rx + gx_in];
     };
 
-    int r1[K], rlo[K], rhi[K], raw[K];
+    // The LRC gathers (dR and cR at column j - d/16 of the same row) depend on the disparity of the
+    // window's CENTRE row, which this thread loaded itself RT rows before the window completes.  They
+    // are issued for a whole group of rows as soon as the group's values have arrived and consumed as
+    // the windows complete, so a group pays one memory latency instead of two per row.
+    int r1[K], rlo[K], rhi[K];
     int S1 = 0, Slo = 0, Shi = 0;
-    int nxt[U];
+    int nxt[U], cur[U];
+    int gd[U]; float gc[U];                                       // gathered dR / cR of this group's centre rows
+    int cd[CR], cdr[CR]; float ccr[CR];                           // carried over: last RT centre rows of the previous group
+#pragma unroll
+    for (int k = 0; k < CR; k++) { cd[k] = 0; cdr[k] = 0; ccr[k] = 0.0f; }
 #pragma unroll
     for (int s = 0; s < U; s++) nxt[s] = (s < nrows) ? load(s) : 0;
     for (int n0 = 0; n0 < nrows; n0 += U) {
-        int cur[U];
 #pragma unroll
-        for (int s = 0; s < U; s++) { cur[s] = nxt[s]; nxt[s] = (n0 + U + s < nrows) ? load(n0 + U + s) : 0; }
+        for (int s = 0; s < U; s++) cur[s] = nxt[s];
+#pragma unroll
+        for (int s = 0; s < U; s++) {                             // gathers for centre rows n0 .. n0+U-1
+            const int n = n0 + s;
+            gd[s] = 0; gc[s] = 0.0f;
+            if (writer && n >= RT && n < nrows - RT) {
+                const int ridx = j_abs - (cur[s] >> 4);           // DF.cpp:331
+                if (ridx >= a.rrx && ridx < right_end) {
+                    const int i_abs = g.ry + y_out0 + n - RT;
+                    gd[s] = reinterpret_cast<const int16_t*>(baseR + (ptrdiff_t)i_abs * a.sR)[ridx];
+                    gc[s] = cR[(size_t)i_abs * g.W + ridx];
+                }
+            }
+        }
+#pragma unroll
+        for (int s = 0; s < U; s++) nxt[s] = (n0 + U + s < nrows) ? load(n0 + U + s) : 0;
 #pragma unroll
         for (int s = 0; s < U; s++) {
             const int n = n0 + s;
             const int slot = s % K;
-            const int cslot = (s + K - RT) % K;                   // slot of the window's centre row n-RT
-            if (n < nrows) {
+            if (n < nrows) {                                     // block-uniform
                 rowbuf[n & 1][tid] = cur[s];
                 lds_barrier();
                 int h1 = 0, hlo = 0, hhi = 0;
@@ -249,25 +272,24 @@ __global__ void __launch_bounds__(NT) conf_left_kernel(ConfLeftArgs a)
                     }
                 }
                 if (n >= K) { S1 -= r1[slot]; Slo -= rlo[slot]; Shi -= rhi[slot]; }
-                r1[slot] = h1; rlo[slot] = hlo; rhi[slot] = hhi; raw[slot] = cur[s];
+                r1[slot] = h1; rlo[slot] = hlo; rhi[slot] = hhi;
                 S1 += h1; Slo += hlo; Shi += hhi;
-                if (n >= 2 * RT && writer) {
-                    const int oy = y_out0 + n - 2 * RT;           // ROI row; the centre row is never a reflected one
+                if (n >= 2 * RT && writer) {                     // window centred on input row n-RT is complete
+                    const int oy = y_out0 + n - 2 * RT;
                     const int i_abs = g.ry + oy;
                     const float mean = (float)((double)S1 * scale);
                     const float sq = (float)(((double)Shi * 65536.0 + (double)Slo) * scale);
                     const float variance = sq - mean * mean;      // DF.cpp:369
                     float c = 1.0f - a.roll_off * variance;       // DF.cpp:370
                     c = c < 0.0f ? 0.0f : c;
-                    const int d = raw[cslot];
+                    // centre row's own disparity and its gathers: this group's slot s-RT, or carried over
+                    const int d = (s >= RT) ? cur[(s >= RT) ? s - RT : 0] : cd[(s < RT) ? s : 0];
+                    const int dr = (s >= RT) ? gd[(s >= RT) ? s - RT : 0] : cdr[(s < RT) ? s : 0];
+                    const float b = (s >= RT) ? gc[(s >= RT) ? s - RT : 0] : ccr[(s < RT) ? s : 0];
                     const int ridx = j_abs - (d >> 4);            // DF.cpp:331
                     if (ridx >= a.rrx && ridx < right_end) {
-                        const int dr = reinterpret_cast<const int16_t*>(baseR + (ptrdiff_t)i_abs * a.sR)[ridx];
-                        if (abs(d + dr) < a.thresh) {             // DF.cpp:334
-                            const float b = cR[(size_t)i_abs * g.W + ridx];
-                            c = b < c ? b : c;                    // DF.cpp:335
-                        } else
-                            c = 0.0f;                             // DF.cpp:337
+                        if (abs(d + dr) < a.thresh) c = b < c ? b : c;   // DF.cpp:334-335
+                        else c = 0.0f;                                   // DF.cpp:337
                     }
                     c = 255.0f * c;                               // DF.cpp:209
                     conf[(size_t)i_abs * g.W + j_abs] = c;
@@ -279,6 +301,8 @@ __global__ void __launch_bounds__(NT) conf_left_kernel(ConfLeftArgs a)
                 }
             }
         }
+#pragma unroll
+        for (int k = 0; k < RT; k++) { cd[k] = cur[U - RT + k]; cdr[k] = gd[U - RT + k]; ccr[k] = gc[U - RT + k]; }
     }
 }
 

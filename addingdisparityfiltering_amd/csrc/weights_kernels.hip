@@ -115,11 +115,101 @@ __global__ void __launch_bounds__(NT) weights_kernel(WeightArgs a)
     }
 }
 
+// ---------------------------------------------------------------------------------------
+// Row-major outputs (wave solver): a block walks down a strip of 256 columns.  Each row's guide bytes
+// are fetched once as aligned dwords (prefetched a group of rows ahead), exchanged through a
+// double-buffered LDS row; a thread keeps its own pixel of the previous row in registers, so a row
+// costs CH + CH LDS byte reads, two table look-ups (head of the LUT cached in LDS once per block) and
+// two coalesced 1 KiB stores: Chor of this row and Cvert of the previous one.
+// ---------------------------------------------------------------------------------------
+constexpr int WS_ROWS = 128;
+constexpr int WS_U = 16;
+
+template <int CH>
+__global__ void __launch_bounds__(NT) weights_stream_kernel(WeightArgs a)
+{
+    constexpr int ROWW = ((NT + 1) * CH + 3) / 4 + 1;          // dwords per staged row (incl. misalignment)
+    __shared__ unsigned rowbuf[2][ROWW + 3];
+    __shared__ float lut_head[LUT_HEAD];
+    const Geom& g = a.g;
+    const int tid = threadIdx.x;
+    const int x0 = blockIdx.x * NT, y0 = blockIdx.y * WS_ROWS;
+    const size_t pz = blockIdx.z;
+    const unsigned char* gp = a.guide + (ptrdiff_t)pz * a.pair_stride + (ptrdiff_t)(g.rx + x0) * CH;
+    const int j = x0 + tid;
+    const bool okx = j < g.rw;
+    const int last_px = min(x0 + NT, g.rw - 1);                // right neighbour of the last ROI column is unused
+    const int need = (last_px - x0 + 1) * CH;                  // bytes needed per row
+    const int nrows = min(WS_ROWS, g.rh - y0) + 1;             // one extra row feeds the last vertical difference
+    float* chor = a.chor + pz * g.plane;
+    float* cvert = a.cvert + pz * g.plane;
+
+    for (int q = tid; q < LUT_HEAD; q += NT) lut_head[q] = a.lut[q];
+
+    // row n of the block = ROI row min(y0+n, rh-1); returns this thread's aligned dword (or 0)
+    auto row_ptr = [&](int n) { return gp + (ptrdiff_t)(g.ry + min(y0 + n, g.rh - 1)) * a.stride; };
+    auto load = [&](int n) -> unsigned {
+        const unsigned char* rp = row_ptr(n);
+        const int m = (int)(reinterpret_cast<uintptr_t>(rp) & 3u);
+        const int nw = (m + need + 3) >> 2;
+        return tid < nw ? reinterpret_cast<const unsigned*>(rp - m)[tid] : 0u;
+    };
+    auto lookup = [&](int idx) -> float {
+        float w = lut_head[min(idx, LUT_HEAD - 1)];
+        if (idx >= LUT_HEAD) w = a.lut[idx];                   // rare: strong colour edge
+        return w;
+    };
+
+    int prev[CH];
+#pragma unroll
+    for (int c = 0; c < CH; c++) prev[c] = 0;
+    unsigned nxt[WS_U], cur[WS_U];
+#pragma unroll
+    for (int s = 0; s < WS_U; s++) nxt[s] = (s < nrows) ? load(s) : 0u;
+    for (int n0 = 0; n0 < nrows; n0 += WS_U) {
+#pragma unroll
+        for (int s = 0; s < WS_U; s++) { cur[s] = nxt[s]; nxt[s] = (n0 + WS_U + s < nrows) ? load(n0 + WS_U + s) : 0u; }
+#pragma unroll
+        for (int s = 0; s < WS_U; s++) {
+            const int n = n0 + s;
+            if (n < nrows) {                                   // block-uniform
+                if (tid < ROWW) rowbuf[n & 1][tid] = cur[s];
+                asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+                const int m = (int)(reinterpret_cast<uintptr_t>(row_ptr(n)) & 3u);
+                const unsigned char* p = reinterpret_cast<const unsigned char*>(rowbuf[n & 1]) + m + tid * CH;
+                int px[CH], hidx = 0, vidx = 0;
+#pragma unroll
+                for (int c = 0; c < CH; c++) {
+                    px[c] = p[c];
+                    const int dh = px[c] - (int)p[CH + c];
+                    const int dv = prev[c] - px[c];
+                    hidx += dh * dh; vidx += dv * dv;
+                    prev[c] = px[c];
+                }
+                const int i = y0 + n;                          // ROI row of this input row (when n < nrows-1)
+                if (okx) {
+                    if (n < nrows - 1)                         // Chor of this row, FGS.cpp:607-614
+                        chor[(size_t)i * g.pw + j] = (j == g.rw - 1) ? 0.0f : lookup(hidx);
+                    if (n >= 1)                                // Cvert of the previous row, FGS.cpp:635-660
+                        cvert[(size_t)(i - 1) * g.pw + j] = (i - 1 == g.rh - 1) ? 0.0f : lookup(vidx);
+                }
+            }
+        }
+    }
+}
+
 } // namespace
 
 hipError_t launch_weights(const WeightArgs& a, int n_pairs, hipStream_t st)
 {
     if (a.cvert_orient != ORIENT_N) return hipErrorInvalidValue;
+    if (a.chor_orient == ORIENT_N) {   // wave solver: streaming kernel
+        dim3 sgrid((a.g.rw + NT - 1) / NT, (a.g.rh + WS_ROWS - 1) / WS_ROWS, n_pairs);
+        if (a.ch == 1) hipLaunchKernelGGL(weights_stream_kernel<1>, sgrid, dim3(NT), 0, st, a);
+        else if (a.ch == 3) hipLaunchKernelGGL(weights_stream_kernel<3>, sgrid, dim3(NT), 0, st, a);
+        else return hipErrorInvalidValue;
+        return hipGetLastError();
+    }
     dim3 grid((a.g.rw + TX - 1) / TX, (a.g.rh + TY - 1) / TY, n_pairs);
     if (a.ch == 1) hipLaunchKernelGGL(weights_kernel<1>, grid, dim3(NT), 0, st, a);
     else if (a.ch == 3) hipLaunchKernelGGL(weights_kernel<3>, grid, dim3(NT), 0, st, a);

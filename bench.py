@@ -138,6 +138,7 @@ def main():
     f.setDepthDiscontinuityRadius(radius)
     f.setSolver(adf.SOLVER_WAVE if args.solver == "wave" else adf.SOLVER_EXACT)
 
+    f.enableProfiling(True)   # also during warm-up, so that the event pool exists before the timed region
     for _ in range(max(args.warmup, 0)):
         f.filter(dl, view, out, dr, roi)
     torch.cuda.synchronize()
