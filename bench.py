@@ -196,33 +196,50 @@ def main():
 
     mpx = n_total * W * H * args.steps / elapsed / 1e6
     P = roi[2] * roi[3]
-    # dominant kernel: the solve pass with two right-hand sides writing planes (5 of the 6 passes)
-    dom = [prof[k] for k in ("pass_h", "pass_v") if k in prof]
-    launches = sum(d["launches"] for d in dom)
-    dom_ms = sum(d["total_ms"] for d in dom)
     alg_per_launch = 20.0 * P * pairs          # (4 + 8R) bytes per ROI pixel, R = 2
-    avg_ms = dom_ms / max(launches, 1)
+
+    # kernel names as rocprofv3 prints them (chunk lengths follow the launchers' buckets)
+    def bucket(v, bs):
+        return next(b for b in bs if v <= b)
+    if args.solver == "wave":
+        mh = bucket((roi[2] + 63) // 64, (4, 8, 16, 20, 28, 40, 56, 64))
+        mv = bucket((roi[3] + 63) // 64, (2, 4, 8, 12, 18, 26, 34))
+        names = {"pass_h": "wave_hpass_kernel<%d, 2, false>" % mh, "pass_v": "wave_vpass_kernel<%d, 2, 0>" % mv}
+    else:
+        names = {"pass_h": "exact_pass_kernel<2, 0>", "pass_v": "exact_pass_kernel<2, 0>"}
+
+    def pass_stats(classes):
+        d = [prof[k] for k in classes if k in prof]
+        n = sum(x["launches"] for x in d)
+        ms = sum(x["total_ms"] for x in d) / max(n, 1)
+        return n, ms
+    # dominant kernel = the solve-pass kernel with the largest share of the step; both passes of the
+    # exact solver are one kernel, the wave solver has a row kernel and a column kernel
+    if names["pass_h"] == names["pass_v"]:
+        dom_classes = ["pass_h", "pass_v"]
+    else:
+        dom_classes = [max(("pass_h", "pass_v"), key=lambda k: prof.get(k, {}).get("total_ms", 0.0))]
+    launches, avg_ms = pass_stats(dom_classes)
     achieved = alg_per_launch / (avg_ms * 1e-3) / 1e9 if launches else 0.0
     traffic = None
     tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     if os.path.exists(tpath):
         try:
-            t = json.load(open(tpath))
-            key = "%s_cfg%d_pairs%d" % (args.solver, args.config, pairs)
-            traffic = t.get(key, {}).get("bytes_per_launch")
+            t = json.load(open(tpath)).get("%s_cfg%d" % (args.solver, args.config), {})
+            per_pair = t.get(names[dom_classes[0]], {}).get("bytes_per_pair")
+            traffic = None if per_pair is None else per_pair * pairs
         except Exception:
             traffic = None
-    roofline = {"bound": "hbm", "kernel": "exact_pass_kernel<2,0>" if args.solver == "exact" else "wave_pass_kernel",
-                "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                "launches": launches, "avg_launch_ms": round(avg_ms, 4),
-                "alg_bytes_per_launch": alg_per_launch}
+    roofline = {"bound": "hbm", "kernel": names[dom_classes[0]], "achieved": round(achieved, 1),
+                "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                "launches": launches, "avg_launch_ms": round(avg_ms, 4), "alg_bytes_per_launch": alg_per_launch}
     for name in ("pass_h", "pass_v"):
         if name in prof and prof[name]["launches"]:
             d = prof[name]
             ms = d["total_ms"] / d["launches"]
             roofline["row_pass" if name == "pass_h" else "col_pass"] = {
-                "avg_launch_ms": round(ms, 4), "achieved": round(alg_per_launch / (ms * 1e-3) / 1e9, 1),
+                "kernel": names[name], "launches": d["launches"], "avg_launch_ms": round(ms, 4),
+                "achieved": round(alg_per_launch / (ms * 1e-3) / 1e9, 1),
                 "frac": round(alg_per_launch / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                 "moved_GBs": round(d["moved_bytes"] / d["launches"] / (ms * 1e-3) / 1e9, 1)}
     kernels = {k: {"launches": v["launches"], "ms_per_step": round(v["total_ms"] / args.steps, 4),
