@@ -14,11 +14,16 @@ from .ximgproc import (  # noqa: F401
     StereoBM,
     StereoMatcher,
     StereoSGBM,
+    UNKNOWN_DISPARITY,
+    computeBadPixelPercent,
+    computeMSE,
     createDisparityWLSFilter,
     createDisparityWLSFilterGeneric,
     createFastGlobalSmootherFilter,
     createRightMatcher,
     fastGlobalSmootherFilter,
+    getDisparityVis,
+    readGT,
 )
 
 __version__ = "0.1.0"

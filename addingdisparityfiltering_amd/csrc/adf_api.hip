@@ -31,6 +31,11 @@ static int fail(int code, const char* fmt, ...)
     return code;
 }
 
+// error reporting for the other translation units (declared in adf_internal.h)
+namespace adf {
+int set_error(int code, const char* msg) { return fail(code, "%s", msg); }
+}
+
 #define HIP_TRY(expr)                                                                         \
     do {                                                                                      \
         hipError_t e_ = (expr);                                                               \

@@ -118,6 +118,9 @@ struct WavePassArgs {
     float lambda;
 };
 
+// Records the calling thread's last error message (adf_last_error) and returns `code`.
+int set_error(int code, const char* msg);
+
 // Launchers (defined in the .hip files).  All are asynchronous on `st`.
 hipError_t launch_discontinuity(const DiscArgs& a, int n_pairs, hipStream_t st);
 hipError_t launch_lrc_prologue(const LrcArgs& a, int n_pairs, hipStream_t st);

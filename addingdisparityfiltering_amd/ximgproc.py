@@ -425,3 +425,81 @@ def createFastGlobalSmootherFilter(guide, lambda_, sigma_color, lambda_attenuati
 def fastGlobalSmootherFilter(guide, src, lambda_, sigma_color, lambda_attenuation=0.25, num_iter=3, dst=None):
     """EF.hpp:413, FGS.cpp:687-691."""
     return createFastGlobalSmootherFilter(guide, lambda_, sigma_color, lambda_attenuation, num_iter).filter(src, dst)
+
+
+# ---------------------------------------------------------------------------------------------
+# Evaluation utilities (DF.hpp:163-204, DF.cpp:460-556)
+# ---------------------------------------------------------------------------------------------
+UNKNOWN_DISPARITY = 16320  # DF.cpp:460
+
+
+def readGT(src_path):
+    """DF.hpp:163 / DF.cpp:462-495: ground-truth disparity (x16) from a Middlebury (8-bit gray: value*16,
+    0 -> unknown) or MPI-Sintel (8-bit colour: 64*R + G/4) image.  Returns (status, map); status 0 = ok,
+    1 = unsupported image, like the reference.  Decoding uses Pillow (the reference uses cv::imread)."""
+    try:
+        from PIL import Image
+
+        im = Image.open(src_path)
+        im.load()
+    except Exception:
+        return 1, np.zeros((0, 0), np.int16)
+    if im.mode in ("RGB", "RGBA") and im.mode == "RGB":
+        a = np.asarray(im, np.int32)                       # PIL is RGB; the reference indexes BGR val[2]=R, val[1]=G
+        return 0, (64 * a[:, :, 0] + a[:, :, 1] // 4).astype(np.int16)
+    if im.mode == "L":
+        a = np.asarray(im, np.int32)
+        return 0, np.where(a == 0, UNKNOWN_DISPARITY, 16 * a).astype(np.int16)
+    return 1, np.zeros((im.size[1], im.size[0]), np.int16)
+
+
+def _eval_pair(GT, src, ROI):
+    g = _Image(GT, np.int16, "GT", False)
+    s = _Image(src, np.int16, "src", False)
+    if (g.h, g.w) != (s.h, s.w):
+        raise AdfError(_lib.ADF_ESIZE, "GT and src differ in size")   # DF.cpp:501
+    if g.device != s.device:
+        raise AdfError(_lib.ADF_EBADARG, "GT and src must both be numpy arrays or both be CUDA tensors")
+    return g, s, _as_rect(ROI)
+
+
+def computeMSE(GT, src, ROI=None):
+    """DF.hpp:176, DF.cpp:497-517."""
+    g, s, roi = _eval_pair(GT, src, ROI)
+    out = C.c_double()
+    args = [C.c_void_p(g.ptr), g.stride, C.c_void_p(s.ptr), s.stride, g.w, g.h,
+            C.byref(roi) if roi is not None else None, C.byref(out)]
+    if g.device:
+        _lib.check(_lib.lib().adf_compute_mse_device(*args, _stream_of(g)))
+    else:
+        _lib.check(_lib.lib().adf_compute_mse_host(*args))
+    return out.value
+
+
+def computeBadPixelPercent(GT, src, ROI=None, thresh=24):
+    """DF.hpp:190, DF.cpp:519-539."""
+    g, s, roi = _eval_pair(GT, src, ROI)
+    out = C.c_double()
+    args = [C.c_void_p(g.ptr), g.stride, C.c_void_p(s.ptr), s.stride, g.w, g.h,
+            C.byref(roi) if roi is not None else None, int(thresh), C.byref(out)]
+    if g.device:
+        _lib.check(_lib.lib().adf_compute_bad_pixel_percent_device(*args, _stream_of(g)))
+    else:
+        _lib.check(_lib.lib().adf_compute_bad_pixel_percent_host(*args))
+    return out.value
+
+
+def getDisparityVis(src, dst=None, scale=1.0):
+    """DF.hpp:202, DF.cpp:541-556."""
+    s = _Image(src, np.int16, "src", False)
+    if dst is None:
+        dst = torch.empty((s.h, s.w), dtype=torch.uint8, device=s.keep.device) if s.device else np.empty((s.h, s.w), np.uint8)
+    d = _Image(dst, np.uint8, "dst", False)
+    if (d.h, d.w) != (s.h, s.w) or d.device != s.device:
+        raise AdfError(_lib.ADF_ESIZE, "dst has the wrong size or placement")
+    args = [C.c_void_p(s.ptr), s.stride, C.c_void_p(d.ptr), d.stride, s.w, s.h, float(scale)]
+    if s.device:
+        _lib.check(_lib.lib().adf_get_disparity_vis_device(*args, _stream_of(s)))
+    else:
+        _lib.check(_lib.lib().adf_get_disparity_vis_host(*args))
+    return dst

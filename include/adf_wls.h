@@ -166,6 +166,30 @@ void adf_fgs_destroy(adf_fgs_t* h);
 int adf_fgs_filter_host(adf_fgs_t* h, const void* src, ptrdiff_t src_stride, void* dst,
                         ptrdiff_t dst_stride, int depth, int channels);
 
+/* ---------------- evaluation utilities (DF.hpp:163-204) ---------------- */
+
+#define ADF_UNKNOWN_DISPARITY 16320 /* DF.cpp:460 */
+
+/* computeMSE(GT, src, ROI) (DF.hpp:176, DF.cpp:497-517): mean of (GT-src)^2 over ROI pixels whose
+ * ground truth is known (!= 16320), divided by 256 (disparities are scaled by 16).  CV_16SC1 maps of
+ * equal size W x H; `*_device` takes device pointers and synchronises `stream` to return the value. */
+int adf_compute_mse_host(const int16_t* gt, ptrdiff_t gt_stride, const int16_t* src, ptrdiff_t src_stride,
+                         int W, int H, const adf_rect* roi, double* mse);
+int adf_compute_mse_device(const int16_t* gt, ptrdiff_t gt_stride, const int16_t* src, ptrdiff_t src_stride,
+                           int W, int H, const adf_rect* roi, double* mse, void* stream);
+/* computeBadPixelPercent(GT, src, ROI, thresh = 24) (DF.hpp:190, DF.cpp:519-539): percentage of known
+ * ROI pixels with |GT-src| >= thresh. */
+int adf_compute_bad_pixel_percent_host(const int16_t* gt, ptrdiff_t gt_stride, const int16_t* src, ptrdiff_t src_stride,
+                                       int W, int H, const adf_rect* roi, int thresh, double* percent);
+int adf_compute_bad_pixel_percent_device(const int16_t* gt, ptrdiff_t gt_stride, const int16_t* src, ptrdiff_t src_stride,
+                                         int W, int H, const adf_rect* roi, int thresh, double* percent, void* stream);
+/* getDisparityVis(src, dst, scale = 1.0) (DF.hpp:202, DF.cpp:541-556): CV_8U visualisation,
+ * saturate_cast<uchar>(scale*src/16.0), unknown disparities -> 0. */
+int adf_get_disparity_vis_host(const int16_t* src, ptrdiff_t src_stride, uint8_t* dst, ptrdiff_t dst_stride,
+                               int W, int H, double scale);
+int adf_get_disparity_vis_device(const int16_t* src, ptrdiff_t src_stride, uint8_t* dst, ptrdiff_t dst_stride,
+                                 int W, int H, double scale, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

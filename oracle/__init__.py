@@ -65,6 +65,11 @@ def lib():
         L.adf_oracle_wls_filter.argtypes = [C.POINTER(Params), vp, pd, vp, pd, i, i, i, vp, pd,
                                             i, i, i, i, vp, pd, vp]
         L.adf_oracle_wls_filter.restype = i
+        L.adf_oracle_compute_mse.argtypes = [vp, vp, i, i, i, i, i, i]
+        L.adf_oracle_compute_mse.restype = d
+        L.adf_oracle_bad_pixel_percent.argtypes = [vp, vp, i, i, i, i, i, i, i]
+        L.adf_oracle_bad_pixel_percent.restype = d
+        L.adf_oracle_disparity_vis.argtypes = [vp, vp, i, i, d]
         L.adf_oracle_sat16.argtypes = [f]
         L.adf_oracle_sat16.restype = C.c_int16
         _lib = L
@@ -190,3 +195,22 @@ def wls_filter(dispL, guide, dispR, roi, params=None, want_conf=True):
 
 def sat16(v):
     return int(lib().adf_oracle_sat16(float(v)))
+
+
+def compute_mse(gt, src, roi):
+    g = np.ascontiguousarray(gt, np.int16); s = np.ascontiguousarray(src, np.int16)
+    H, W = g.shape
+    return lib().adf_oracle_compute_mse(_p(g), _p(s), W, H, roi[0], roi[1], roi[2], roi[3])
+
+
+def bad_pixel_percent(gt, src, roi, thresh=24):
+    g = np.ascontiguousarray(gt, np.int16); s = np.ascontiguousarray(src, np.int16)
+    H, W = g.shape
+    return lib().adf_oracle_bad_pixel_percent(_p(g), _p(s), W, H, roi[0], roi[1], roi[2], roi[3], thresh)
+
+
+def disparity_vis(src, scale=1.0):
+    s = np.ascontiguousarray(src, np.int16)
+    out = np.empty(s.shape, np.uint8)
+    lib().adf_oracle_disparity_vis(_p(s), _p(out), s.shape[1], s.shape[0], float(scale))
+    return out

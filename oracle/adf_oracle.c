@@ -555,3 +555,51 @@ int adf_oracle_wls_filter(const adf_oracle_params* p, const int16_t* dispL, ptrd
     free(planes);
     return rc;
 }
+
+/* ------------------------------------------------------------------ */
+/* N3: evaluation utilities, DF.cpp:460-556                             */
+/* ------------------------------------------------------------------ */
+#define ADF_UNKNOWN_DISPARITY 16320 /* DF.cpp:460 */
+
+double adf_oracle_compute_mse(const int16_t* gt, const int16_t* src, int W, int H, int rx, int ry, int rw, int rh)
+{
+    (void)H;
+    double res = 0; long long cnt = 0;
+    for (int i = 0; i < rh; i++)
+        for (int j = 0; j < rw; j++) {
+            int g = gt[(size_t)(ry + i) * W + rx + j], s = src[(size_t)(ry + i) * W + rx + j];
+            if (g != ADF_UNKNOWN_DISPARITY) {                    /* DF.cpp:507 */
+                long long d = (long long)g - s;                  /* the reference squares in int; 64 bits avoid its overflow */
+                res += (double)(d * d);
+                cnt++;
+            }
+        }
+    return res / ((double)cnt * 256.0);                          /* DF.cpp:515 */
+}
+
+double adf_oracle_bad_pixel_percent(const int16_t* gt, const int16_t* src, int W, int H, int rx, int ry, int rw, int rh, int thresh)
+{
+    (void)H;
+    long long bad = 0, cnt = 0;
+    for (int i = 0; i < rh; i++)
+        for (int j = 0; j < rw; j++) {
+            int g = gt[(size_t)(ry + i) * W + rx + j], s = src[(size_t)(ry + i) * W + rx + j];
+            if (g != ADF_UNKNOWN_DISPARITY) {
+                if (abs(g - s) >= thresh) bad++;                 /* DF.cpp:531 */
+                cnt++;
+            }
+        }
+    return (100.0 * (double)bad) / (double)cnt;                  /* DF.cpp:538 */
+}
+
+void adf_oracle_disparity_vis(const int16_t* src, uint8_t* dst, int W, int H, double scale)
+{
+    for (size_t k = 0; k < (size_t)W * H; k++) {
+        if (src[k] == ADF_UNKNOWN_DISPARITY) dst[k] = 0;         /* DF.cpp:551-552 */
+        else {
+            double t = scale * src[k] / 16.0;                    /* saturate_cast<uchar>(double) = cvRound + clamp */
+            long r = (t >= -2147483648.0 && t < 2147483648.0) ? lrint(t) : (long)INT_MIN;
+            dst[k] = (uint8_t)(r < 0 ? 0 : r > 255 ? 255 : r);
+        }
+    }
+}

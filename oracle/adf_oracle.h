@@ -119,6 +119,11 @@ int adf_oracle_wls_filter(const adf_oracle_params* p,
                           int rx, int ry, int rw, int rh,
                           int16_t* out, ptrdiff_t strideO, float* conf_out);
 
+/* DF.cpp:497-517 computeMSE, :519-539 computeBadPixelPercent, :541-556 getDisparityVis (dense rows). */
+double adf_oracle_compute_mse(const int16_t* gt, const int16_t* src, int W, int H, int rx, int ry, int rw, int rh);
+double adf_oracle_bad_pixel_percent(const int16_t* gt, const int16_t* src, int W, int H, int rx, int ry, int rw, int rh, int thresh);
+void adf_oracle_disparity_vis(const int16_t* src, uint8_t* dst, int W, int H, double scale);
+
 /* saturate_cast<short>(float) = cvRound + clamp (DF.cpp:296, FGS.cpp:216);
  * exported so tests can probe the rounding convention directly. */
 int16_t adf_oracle_sat16(float v);
