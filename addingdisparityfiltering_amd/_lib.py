@@ -36,6 +36,8 @@ class Rect(C.Structure):
 _vp, _i, _d, _pd, _sz = C.c_void_p, C.c_int, C.c_double, C.c_ssize_t, C.c_size_t
 _FILTER_DEV = [_vp, _i, _vp, _pd, _pd, _vp, _pd, _pd, _i, _i, _i, _vp, _pd, _pd, _vp, _pd, _pd,
                C.POINTER(Rect), _vp]
+_FILTER_SCALED_DEV = [_vp, _i, _vp, _pd, _pd, _i, _i, _vp, _pd, _pd, _i, _i, _i, _vp, _pd, _pd, _vp, _pd, _pd,
+                      C.POINTER(Rect), _vp]
 SYMBOLS = [
     ("adf_version", _i, []),
     ("adf_last_error", C.c_char_p, []),
@@ -56,6 +58,8 @@ SYMBOLS = [
     ("adf_wls_get_last_solver", _i, [_vp, C.POINTER(_i)]),
     ("adf_wls_filter_device", _i, _FILTER_DEV),
     ("adf_wls_filter_host", _i, _FILTER_DEV[:-1]),
+    ("adf_wls_filter_scaled_device", _i, _FILTER_SCALED_DEV),
+    ("adf_wls_filter_scaled_host", _i, _FILTER_SCALED_DEV[:-1]),
     ("adf_wls_get_confidence_device", _i, [_vp, _i, _vp, _pd, _vp]),
     ("adf_wls_get_confidence_host", _i, [_vp, _i, _vp, _pd]),
     ("adf_wls_get_roi", _i, [_vp, C.POINTER(Rect)]),

@@ -276,6 +276,7 @@ struct adf_wls {
     DevBuf ws;    // per-chunk workspace
     DevBuf conf;  // confidence maps of the last call (n_pairs full frames)
     DevBuf stage; // host-pointer path staging
+    DevBuf scaled; // down-scaled path: resized disparity + low-resolution confidence scratch
     size_t ws_limit = (size_t)64 << 30;
     Profiler prof;
     // (geometry, solver) the workspace planes were last laid out for; a change re-zeroes them so that
@@ -309,7 +310,7 @@ extern "C" void adf_wls_destroy(adf_wls_t* h)
 {
     if (!h) return;
     DeviceScope ds(h->device);
-    h->lut.dev.release(); h->ws.release(); h->conf.release(); h->stage.release();
+    h->lut.dev.release(); h->ws.release(); h->conf.release(); h->stage.release(); h->scaled.release();
     h->prof.destroy();
     delete h;
 }
@@ -346,7 +347,7 @@ extern "C" int adf_wls_get_last_solver(const adf_wls_t* h, int* v) { NEED_HANDLE
 extern "C" int adf_wls_get_roi(const adf_wls_t* h, adf_rect* roi) { NEED_HANDLE(h); if (roi) *roi = h->roi; return ADF_OK; }
 extern "C" size_t adf_wls_workspace_bytes(const adf_wls_t* h)
 {
-    return h ? h->ws.bytes + h->conf.bytes + h->stage.bytes + h->lut.dev.bytes : 0;
+    return h ? h->ws.bytes + h->conf.bytes + h->stage.bytes + h->scaled.bytes + h->lut.dev.bytes : 0;
 }
 
 extern "C" int adf_wls_sync(adf_wls_t* h, void* stream)
@@ -365,15 +366,16 @@ static size_t wls_pair_ws_bytes(const Geom& g, bool conf, bool wave)
     return planes * g.plane * sizeof(float) + (conf ? 2 * g.frame * sizeof(float) : 0);
 }
 
-extern "C" int adf_wls_filter_device(adf_wls_t* h, int n_pairs,
-                                     const int16_t* dispL, ptrdiff_t sL, ptrdiff_t psL,
-                                     const uint8_t* view, ptrdiff_t sG, ptrdiff_t psG, int gch, int W, int H,
-                                     int16_t* out, ptrdiff_t sO, ptrdiff_t psO,
-                                     const int16_t* dispR, ptrdiff_t sR, ptrdiff_t psR,
-                                     const adf_rect* roi_in, void* stream)
+// conf_given: h->conf already holds the view-sized confidence planes of all pairs (down-scaled path,
+// DF.cpp:274); the confidence kernels are skipped and dispR is not used.
+static int wls_filter_impl(adf_wls_t* h, int n_pairs,
+                           const int16_t* dispL, ptrdiff_t sL, ptrdiff_t psL,
+                           const uint8_t* view, ptrdiff_t sG, ptrdiff_t psG, int gch, int W, int H,
+                           int16_t* out, ptrdiff_t sO, ptrdiff_t psO,
+                           const int16_t* dispR, ptrdiff_t sR, ptrdiff_t psR,
+                           const adf_rect* roi_in, bool conf_given, hipStream_t st)
 {
     NEED_HANDLE(h);
-    hipStream_t st = (hipStream_t)stream;
     // DF.cpp:221-222
     if (!dispL || W <= 0 || H <= 0) return fail(ADF_EBADARG, "disparity_map_left is empty");
     if (!view || (gch != 1 && gch != 3)) return fail(ADF_EBADARG, "left_view must be CV_8UC1 or CV_8UC3");
@@ -381,7 +383,7 @@ extern "C" int adf_wls_filter_device(adf_wls_t* h, int n_pairs,
     if (n_pairs < 1) return fail(ADF_EBADARG, "n_pairs must be >= 1");
     if (sL < (ptrdiff_t)W * 2 || sO < (ptrdiff_t)W * 2 || sG < (ptrdiff_t)W * gch)
         return fail(ADF_ESIZE, "row stride smaller than a row");
-    if (h->use_confidence) { // DF.cpp:262-264
+    if (h->use_confidence && !conf_given) { // DF.cpp:262-264
         if (!dispR) return fail(ADF_EBADARG, "disparity_map_right is required with use_confidence");
         if (sR < (ptrdiff_t)W * 2) return fail(ADF_ESIZE, "right disparity stride smaller than a row");
     }
@@ -413,7 +415,7 @@ extern "C" int adf_wls_filter_device(adf_wls_t* h, int n_pairs,
     if (chunk < 1) chunk = 1;
     if (chunk > n_pairs) chunk = n_pairs;
     if ((rc = h->ws.reserve(per_pair * (size_t)chunk, st))) return rc;
-    if (conf && (rc = h->conf.reserve(g.frame * sizeof(float) * (size_t)n_pairs, st))) return rc;
+    if (conf && !conf_given && (rc = h->conf.reserve(g.frame * sizeof(float) * (size_t)n_pairs, st))) return rc;
 
     {
         const long long sig[8] = {W, H, roi.x, roi.y, roi.width, roi.height, (long long)wave * 2 + conf, chunk};
@@ -468,7 +470,23 @@ extern "C" int adf_wls_filter_device(adf_wls_t* h, int n_pairs,
             da.ry = roi.y; da.rw = roi.width; da.rh = roi.height; da.radius = h->disc_radius;
             da.roll_off = h->roll_off; da.W = W; da.frame = g.frame; da.only_view = -1;
             WavePassArgs fuse{};                                            // inputs of a fused first pass
-            if (wave && h->disc_radius <= conf_left_max_radius()) {
+            if (conf_given) {
+                // confidence already resized to the view (DF.cpp:274): only the prologue remains (DF.cpp:286-290)
+                OutsideArgs oa{o, sO, psO, fill, nullptr, g};
+                {
+                    ProfScope ps(prof, K_FILL, 2.0 * (F - P), 2.0 * (F - P), st);
+                    HIP_TRY(launch_outside(oa, n, st));                    // DF.cpp:284
+                }
+                fuse.conf_in = confp; fuse.conf_frame = g.frame; fuse.conf_pitch = W; fuse.conf_x0 = roi.x; fuse.conf_y0 = roi.y;
+                fuse.dl_in = dL; fuse.dl_stride = sL; fuse.dl_pair_stride = psL; fuse.dl_x0 = roi.x; fuse.dl_y0 = roi.y;
+                fuse.len = g.rw;
+                if (!(wave && wave_hpass_can_fuse(fuse))) {
+                    fuse = WavePassArgs{};
+                    PlainPrologueArgs pa{dL, sL, psL, ADF_16S, 1, 0, p.A0, g, orient_h, confp, p.A1};
+                    ProfScope ps(prof, K_PROLOGUE, 14.0 * P, 14.0 * P, st);
+                    HIP_TRY(launch_plain_prologue(pa, n, st));
+                }
+            } else if (wave && h->disc_radius <= conf_left_max_radius()) {
                 // wave path: right map, then left map + LRC + x255 in one sweep (cL never hits memory);
                 // the first horizontal pass forms conf*disp itself when alignment allows
                 da.only_view = 1;
@@ -524,6 +542,133 @@ extern "C" int adf_wls_filter_device(adf_wls_t* h, int n_pairs,
     return ADF_OK;
 }
 
+extern "C" int adf_wls_filter_device(adf_wls_t* h, int n_pairs,
+                                     const int16_t* dispL, ptrdiff_t sL, ptrdiff_t psL,
+                                     const uint8_t* view, ptrdiff_t sG, ptrdiff_t psG, int gch, int W, int H,
+                                     int16_t* out, ptrdiff_t sO, ptrdiff_t psO,
+                                     const int16_t* dispR, ptrdiff_t sR, ptrdiff_t psR,
+                                     const adf_rect* roi_in, void* stream)
+{
+    return wls_filter_impl(h, n_pairs, dispL, sL, psL, view, sG, psG, gch, W, H, out, sO, psO, dispR, sR, psR, roi_in,
+                           false, (hipStream_t)stream);
+}
+
+// Down-scaled disparity path (DF.cpp:224-227, 239-247, 268-277): disparity maps of dW x dH, view and
+// output of W x H.  ROI is in disparity-map coordinates, like the reference's.
+extern "C" int adf_wls_filter_scaled_device(adf_wls_t* h, int n_pairs,
+                                            const int16_t* dispL, ptrdiff_t sL, ptrdiff_t psL, int dW, int dH,
+                                            const uint8_t* view, ptrdiff_t sG, ptrdiff_t psG, int gch, int W, int H,
+                                            int16_t* out, ptrdiff_t sO, ptrdiff_t psO,
+                                            const int16_t* dispR, ptrdiff_t sR, ptrdiff_t psR,
+                                            const adf_rect* roi_in, void* stream)
+{
+    NEED_HANDLE(h);
+    hipStream_t st = (hipStream_t)stream;
+    if (dW == W && dH == H)                                                // DF.cpp:224-227: same size, resize_factor 1
+        return wls_filter_impl(h, n_pairs, dispL, sL, psL, view, sG, psG, gch, W, H, out, sO, psO, dispR, sR, psR, roi_in, false, st);
+    if (!dispL || dW <= 0 || dH <= 0 || W <= 0 || H <= 0) return fail(ADF_EBADARG, "disparity_map_left is empty");
+    if (n_pairs < 1) return fail(ADF_EBADARG, "n_pairs must be >= 1");
+    if (sL < (ptrdiff_t)dW * 2) return fail(ADF_ESIZE, "row stride smaller than a row");
+    const bool conf = h->use_confidence;
+    if (conf) {
+        if (!dispR) return fail(ADF_EBADARG, "disparity_map_right is required with use_confidence");
+        if (sR < (ptrdiff_t)dW * 2) return fail(ADF_ESIZE, "right disparity stride smaller than a row");
+        if (h->disc_radius < 0 || h->disc_radius > max_disc_radius())
+            return fail(ADF_EBADARG, "depth discontinuity radius %d outside [0,%d]", h->disc_radius, max_disc_radius());
+    }
+    adf_rect rlo;                                                          // DF.cpp:228-233, disparity-map coordinates
+    if (roi_in && roi_in->width * roi_in->height != 0) rlo = *roi_in;
+    else rlo = adf_rect{h->left_offset, h->top_offset, dW - h->left_offset - h->right_offset, dH - h->top_offset - h->bottom_offset};
+    if (rlo.width <= 0 || rlo.height <= 0 || rlo.x < 0 || rlo.y < 0 || rlo.x + rlo.width > dW || rlo.y + rlo.height > dH)
+        return fail(ADF_ESIZE, "ROI (%d,%d,%d,%d) does not fit a %dx%d map", rlo.x, rlo.y, rlo.width, rlo.height, dW, dH);
+    const float resize_factor = dW / (float)W;                             // DF.cpp:225
+    const float x_ratio = W / (float)dW, y_ratio = H / (float)dH;          // DF.cpp:241-242,270-271
+    adf_rect rhi{(int)(rlo.x * x_ratio), (int)(rlo.y * y_ratio), (int)(rlo.width * x_ratio), (int)(rlo.height * y_ratio)};
+    if (rhi.width <= 0 || rhi.height <= 0 || rhi.x + rhi.width > W || rhi.y + rhi.height > H)
+        return fail(ADF_ESIZE, "scaled ROI (%d,%d,%d,%d) does not fit the %dx%d view", rhi.x, rhi.y, rhi.width, rhi.height, W, H);
+
+    DeviceScope ds(h->device);
+    const size_t lo = (size_t)dW * dH, hi = (size_t)W * H;
+    // scratch: resized disparity (int16, view size) + low-resolution cL, cR, conf (float)
+    const size_t dhi_bytes = (hi * 2 + 255) / 256 * 256;
+    const size_t need = (size_t)n_pairs * (dhi_bytes + (conf ? 3 * lo * sizeof(float) : 0));
+    int rc = h->scaled.reserve(need, st);
+    if (rc) return rc;
+    char* dhi = (char*)h->scaled.p;
+    float* cl = (float*)(dhi + (size_t)n_pairs * dhi_bytes);
+    float* cr = cl + (size_t)n_pairs * lo;
+    float* clo = cr + (size_t)n_pairs * lo;
+    if (conf) {
+        if ((rc = h->conf.reserve(hi * sizeof(float) * (size_t)n_pairs, st))) return rc;
+        const Geom glo = make_geom(dW, dH, rlo.x, rlo.y, rlo.width, rlo.height);
+        const int rrx = dW - (rlo.x + rlo.width);                          // DF.cpp:202
+        DiscArgs da{};
+        da.disp[0] = dispL; da.stride[0] = sL; da.pair_stride[0] = psL; da.rx[0] = rlo.x; da.dst[0] = cl;
+        da.disp[1] = dispR; da.stride[1] = sR; da.pair_stride[1] = psR; da.rx[1] = rrx; da.dst[1] = cr;
+        da.ry = rlo.y; da.rw = rlo.width; da.rh = rlo.height; da.radius = h->disc_radius;
+        da.roll_off = h->roll_off / (resize_factor * resize_factor);        // DF.cpp:359
+        da.W = dW; da.frame = lo; da.only_view = -1;
+        HIP_TRY(launch_discontinuity(da, n_pairs, st));                    // DF.cpp:204
+        LrcArgs la{dispL, sL, psL, dispR, sR, psR, cl, cr, clo, nullptr, 0, 0, 0, nullptr, nullptr, glo, rrx,
+                   (int)(resize_factor * h->lrc_thresh) /* DF.cpp:318 */, ORIENT_N};
+        HIP_TRY(launch_lrc_prologue(la, n_pairs, st));                     // DF.cpp:208-209
+        ResizeArgs rc32{clo, (ptrdiff_t)dW * 4, (ptrdiff_t)(lo * 4), dW, dH, h->conf.p, (ptrdiff_t)W * 4, (ptrdiff_t)(hi * 4), W, H,
+                        (double)dW / W, (double)dH / H, 1.0f, 0};
+        HIP_TRY(launch_resize_linear(rc32, n_pairs, st));                  // DF.cpp:274
+    }
+    ResizeArgs r16{dispL, sL, psL, dW, dH, dhi, (ptrdiff_t)W * 2, (ptrdiff_t)dhi_bytes, W, H, (double)dW / W, (double)dH / H, x_ratio, 1};
+    HIP_TRY(launch_resize_linear(r16, n_pairs, st));                       // DF.cpp:243-244, 272-273
+    rc = wls_filter_impl(h, n_pairs, (const int16_t*)dhi, (ptrdiff_t)W * 2, (ptrdiff_t)dhi_bytes, view, sG, psG, gch, W, H,
+                         out, sO, psO, nullptr, 0, 0, &rhi, conf, st);
+    h->roi = rlo;                                                          // getROI(): valid_disp_ROI (DF.cpp:139)
+    return rc;
+}
+
+extern "C" int adf_wls_filter_scaled_host(adf_wls_t* h, int n_pairs,
+                                          const int16_t* dispL, ptrdiff_t sL, ptrdiff_t psL, int dW, int dH,
+                                          const uint8_t* view, ptrdiff_t sG, ptrdiff_t psG, int gch, int W, int H,
+                                          int16_t* out, ptrdiff_t sO, ptrdiff_t psO,
+                                          const int16_t* dispR, ptrdiff_t sR, ptrdiff_t psR,
+                                          const adf_rect* roi)
+{
+    NEED_HANDLE(h);
+    if (!dispL || !view || !out || W <= 0 || H <= 0 || dW <= 0 || dH <= 0 || n_pairs < 1)
+        return fail(ADF_EBADARG, "adf_wls_filter_host: empty input");
+    if (gch != 1 && gch != 3) return fail(ADF_EBADARG, "left_view must be CV_8UC1 or CV_8UC3");
+    if (h->use_confidence && !dispR) return fail(ADF_EBADARG, "disparity_map_right is required with use_confidence");
+    DeviceScope ds(h->device);
+    hipStream_t st = nullptr;
+    // dense device copies: [dispL | dispR | out | view] per batch
+    const size_t dbytes = (size_t)dW * dH * 2, obytes = (size_t)W * H * 2, gbytes = (size_t)W * H * gch;
+    const size_t dpad = (dbytes + 255) / 256 * 256, opad = (obytes + 255) / 256 * 256, gpad = (gbytes + 255) / 256 * 256;
+    const size_t need = (size_t)n_pairs * (2 * dpad + opad + gpad);
+    int rc = h->stage.reserve(need, st);
+    if (rc) return rc;
+    char* dLd = (char*)h->stage.p;
+    char* dRd = dLd + (size_t)n_pairs * dpad;
+    char* od = dRd + (size_t)n_pairs * dpad;
+    char* gd = od + (size_t)n_pairs * opad;
+    for (int k = 0; k < n_pairs; k++) {
+        HIP_TRY(hipMemcpy2DAsync(dLd + k * dpad, (size_t)dW * 2, (const char*)dispL + (ptrdiff_t)k * psL, sL,
+                                 (size_t)dW * 2, dH, hipMemcpyHostToDevice, st));
+        if (dispR)
+            HIP_TRY(hipMemcpy2DAsync(dRd + k * dpad, (size_t)dW * 2, (const char*)dispR + (ptrdiff_t)k * psR, sR,
+                                     (size_t)dW * 2, dH, hipMemcpyHostToDevice, st));
+        HIP_TRY(hipMemcpy2DAsync(gd + k * gpad, (size_t)W * gch, view + (ptrdiff_t)k * psG, sG,
+                                 (size_t)W * gch, H, hipMemcpyHostToDevice, st));
+    }
+    rc = adf_wls_filter_scaled_device(h, n_pairs, (const int16_t*)dLd, (ptrdiff_t)dW * 2, (ptrdiff_t)dpad, dW, dH,
+                                      (const uint8_t*)gd, (ptrdiff_t)W * gch, (ptrdiff_t)gpad, gch, W, H,
+                                      (int16_t*)od, (ptrdiff_t)W * 2, (ptrdiff_t)opad,
+                                      dispR ? (const int16_t*)dRd : nullptr, (ptrdiff_t)dW * 2, (ptrdiff_t)dpad, roi, st);
+    if (rc) return rc;
+    for (int k = 0; k < n_pairs; k++)
+        HIP_TRY(hipMemcpy2DAsync((char*)out + (ptrdiff_t)k * psO, sO, od + k * opad, (size_t)W * 2,
+                                 (size_t)W * 2, H, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    return ADF_OK;
+}
+
 extern "C" int adf_wls_filter_host(adf_wls_t* h, int n_pairs,
                                    const int16_t* dispL, ptrdiff_t sL, ptrdiff_t psL,
                                    const uint8_t* view, ptrdiff_t sG, ptrdiff_t psG, int gch, int W, int H,
@@ -531,42 +676,8 @@ extern "C" int adf_wls_filter_host(adf_wls_t* h, int n_pairs,
                                    const int16_t* dispR, ptrdiff_t sR, ptrdiff_t psR,
                                    const adf_rect* roi)
 {
-    NEED_HANDLE(h);
-    if (!dispL || !view || !out || W <= 0 || H <= 0 || n_pairs < 1)
-        return fail(ADF_EBADARG, "adf_wls_filter_host: empty input");
-    if (gch != 1 && gch != 3) return fail(ADF_EBADARG, "left_view must be CV_8UC1 or CV_8UC3");
-    if (h->use_confidence && !dispR) return fail(ADF_EBADARG, "disparity_map_right is required with use_confidence");
-    DeviceScope ds(h->device);
-    hipStream_t st = nullptr;
-    // dense device copies: [dispL | dispR | view | out] per batch
-    const size_t dbytes = (size_t)W * H * 2, gbytes = (size_t)W * H * gch;
-    const size_t dpad = (dbytes + 255) / 256 * 256, gpad = (gbytes + 255) / 256 * 256;
-    const size_t need = (size_t)n_pairs * (3 * dpad + gpad);
-    int rc = h->stage.reserve(need, st);
-    if (rc) return rc;
-    char* dLd = (char*)h->stage.p;
-    char* dRd = dLd + (size_t)n_pairs * dpad;
-    char* od = dRd + (size_t)n_pairs * dpad;
-    char* gd = od + (size_t)n_pairs * dpad;
-    for (int k = 0; k < n_pairs; k++) {
-        HIP_TRY(hipMemcpy2DAsync(dLd + k * dpad, (size_t)W * 2, (const char*)dispL + (ptrdiff_t)k * psL, sL,
-                                 (size_t)W * 2, H, hipMemcpyHostToDevice, st));
-        if (dispR)
-            HIP_TRY(hipMemcpy2DAsync(dRd + k * dpad, (size_t)W * 2, (const char*)dispR + (ptrdiff_t)k * psR, sR,
-                                     (size_t)W * 2, H, hipMemcpyHostToDevice, st));
-        HIP_TRY(hipMemcpy2DAsync(gd + k * gpad, (size_t)W * gch, view + (ptrdiff_t)k * psG, sG,
-                                 (size_t)W * gch, H, hipMemcpyHostToDevice, st));
-    }
-    rc = adf_wls_filter_device(h, n_pairs, (const int16_t*)dLd, (ptrdiff_t)W * 2, (ptrdiff_t)dpad,
-                               (const uint8_t*)gd, (ptrdiff_t)W * gch, (ptrdiff_t)gpad, gch, W, H,
-                               (int16_t*)od, (ptrdiff_t)W * 2, (ptrdiff_t)dpad,
-                               dispR ? (const int16_t*)dRd : nullptr, (ptrdiff_t)W * 2, (ptrdiff_t)dpad, roi, st);
-    if (rc) return rc;
-    for (int k = 0; k < n_pairs; k++)
-        HIP_TRY(hipMemcpy2DAsync((char*)out + (ptrdiff_t)k * psO, sO, od + k * dpad, (size_t)W * 2,
-                                 (size_t)W * 2, H, hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipStreamSynchronize(st));
-    return ADF_OK;
+    return adf_wls_filter_scaled_host(h, n_pairs, dispL, sL, psL, W, H, view, sG, psG, gch, W, H, out, sO, psO,
+                                      dispR, sR, psR, roi);
 }
 
 extern "C" int adf_wls_profile_enable(adf_wls_t* h, int on)

@@ -80,6 +80,17 @@ struct PlainPrologueArgs {
     const void* src; ptrdiff_t stride, pair_stride; // bytes
     int depth, cn, c;                               // adf_depth code, channel count, channel index
     float* U0; Geom g; int orient;
+    // optional confidence weighting (down-scaled path, DF.cpp:286-290 on the resized maps):
+    // U0 = conf*float(src), U1 = conf, conf read from a full-frame plane of pitch g.W
+    const float* conf; float* U1;
+};
+
+// cv::resize(INTER_LINEAR) of CV_16SC1 (is16, optional saturating post-scale) or CV_32FC1 images.
+struct ResizeArgs {
+    const void* src; ptrdiff_t sstride, spair; int sw, sh; // bytes
+    void* dst; ptrdiff_t dstride, dpair; int dw, dh;
+    double scale_x, scale_y;                               // sw/dw, sh/dh
+    float post_scale; int is16;
 };
 
 struct WeightArgs {
@@ -129,6 +140,7 @@ hipError_t launch_outside(const OutsideArgs& a, int n_pairs, hipStream_t st);
 int conf_left_max_radius();
 hipError_t launch_plain_prologue(const PlainPrologueArgs& a, int n_pairs, hipStream_t st);
 hipError_t launch_weights(const WeightArgs& a, int n_pairs, hipStream_t st);
+hipError_t launch_resize_linear(const ResizeArgs& a, int n_pairs, hipStream_t st);
 hipError_t launch_exact_pass(const PassArgs& a, int n_rhs, int epilogue, int n_pairs, hipStream_t st);
 hipError_t launch_wave_hpass(const WavePassArgs& a, int n_rhs, int n_pairs, hipStream_t st);
 hipError_t launch_wave_vpass(const WavePassArgs& a, int n_rhs, int epilogue, int n_pairs, hipStream_t st);

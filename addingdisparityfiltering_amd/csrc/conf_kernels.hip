@@ -347,8 +347,8 @@ __global__ void __launch_bounds__(NT) lrc_prologue_kernel(LrcArgs a)
     const float* cL = a.cL + pz * g.frame;
     const float* cR = a.cR + pz * g.frame;
     float* conf = a.conf + pz * g.frame;
-    float* U0 = a.U0 + pz * g.plane;
-    float* U1 = a.U1 + pz * g.plane;
+    float* U0 = a.U0 ? a.U0 + pz * g.plane : nullptr;   // null: confidence only (down-scaled path)
+    float* U1 = a.U0 ? a.U1 + pz * g.plane : nullptr;
     const int j = x0 + tx;
     const int right_end = a.rrx + g.rw;
 
@@ -381,6 +381,7 @@ __global__ void __launch_bounds__(NT) lrc_prologue_kernel(LrcArgs a)
                 reinterpret_cast<int16_t*>(reinterpret_cast<char*>(a.out) + (ptrdiff_t)pz * a.psO +
                                            (ptrdiff_t)i * a.sO)[j] = a.fill;
         }
+        if (!U0) continue;
         if (a.orient == ORIENT_N) {
             if (in_roi) {
                 size_t o = (size_t)(i - g.ry) * g.pw + (j - g.rx);
@@ -391,7 +392,7 @@ __global__ void __launch_bounds__(NT) lrc_prologue_kernel(LrcArgs a)
             t1[tx * (TY + 1) + ty + 4 * kk] = c;
         }
     }
-    if (a.orient == ORIENT_T) {
+    if (U0 && a.orient == ORIENT_T) {
         __syncthreads();
 #pragma unroll
         for (int m = 0; m < TX / 8; m++) {
@@ -409,29 +410,38 @@ __global__ void __launch_bounds__(NT) lrc_prologue_kernel(LrcArgs a)
 __global__ void __launch_bounds__(NT) plain_prologue_kernel(PlainPrologueArgs a)
 {
     __shared__ float t0[TX * (TY + 1)];
+    __shared__ float t1[TX * (TY + 1)];
     const Geom& g = a.g;
     const int tid = threadIdx.x, tx = tid % TX, ty = tid / TX;
     const int x0 = blockIdx.x * TX, y0 = blockIdx.y * TY; // ROI coordinates
     const size_t pz = blockIdx.z;
     const char* pL = reinterpret_cast<const char*>(a.src) + (ptrdiff_t)pz * a.pair_stride;
+    const float* cf = a.conf ? a.conf + pz * g.frame : nullptr;
     float* U0 = a.U0 + pz * g.plane;
+    float* U1 = a.conf ? a.U1 + pz * g.plane : nullptr;
     const int j = x0 + tx;
 #pragma unroll
     for (int kk = 0; kk < TY / 4; kk++) {
         const int i = y0 + ty + 4 * kk;
         const bool ok = i < g.rh && j < g.rw;
-        float u0 = 0.0f;
+        float u0 = 0.0f, u1 = 0.0f;
         if (ok) {
             const char* row = pL + (ptrdiff_t)(g.ry + i) * a.stride;
             const size_t e = (size_t)(g.rx + j) * a.cn + a.c;
             if (a.depth == 3) u0 = (float)reinterpret_cast<const int16_t*>(row)[e];      // CV_16S
             else if (a.depth == 0) u0 = (float)reinterpret_cast<const uint8_t*>(row)[e]; // CV_8U
             else u0 = reinterpret_cast<const float*>(row)[e];                            // CV_32F
+            if (cf) {                                                                    // DF.cpp:286-290
+                u1 = cf[(size_t)(g.ry + i) * g.W + g.rx + j];
+                u0 = u1 * u0;
+            }
         }
         if (a.orient == ORIENT_N) {
-            if (ok) U0[(size_t)i * g.pw + j] = u0;
-        } else
+            if (ok) { U0[(size_t)i * g.pw + j] = u0; if (cf) U1[(size_t)i * g.pw + j] = u1; }
+        } else {
             t0[tx * (TY + 1) + ty + 4 * kk] = u0;
+            t1[tx * (TY + 1) + ty + 4 * kk] = u1;
+        }
     }
     if (a.orient == ORIENT_T) {
         __syncthreads();
@@ -439,7 +449,10 @@ __global__ void __launch_bounds__(NT) plain_prologue_kernel(PlainPrologueArgs a)
         for (int m = 0; m < TX / 8; m++) {
             const int cidx = tid / TY + 8 * m, ridx = tid % TY;
             const int jj = x0 + cidx, ii = y0 + ridx;
-            if (jj < g.rw && ii < g.rh) U0[(size_t)jj * g.ph + ii] = t0[cidx * (TY + 1) + ridx];
+            if (jj < g.rw && ii < g.rh) {
+                U0[(size_t)jj * g.ph + ii] = t0[cidx * (TY + 1) + ridx];
+                if (cf) U1[(size_t)jj * g.ph + ii] = t1[cidx * (TY + 1) + ridx];
+            }
         }
     }
 }

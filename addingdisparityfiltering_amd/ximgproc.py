@@ -206,10 +206,9 @@ class DisparityWLSFilter(DisparityFilter):
         batched = len(disparity_map_left.shape) == 3
         dl = _Image(disparity_map_left, np.int16, "disparity_map_left", batched)
         gv = _Image(left_view, np.uint8, "left_view", batched, allow_channels=(1, 3))
-        if (gv.n, gv.h, gv.w) != (dl.n, dl.h, dl.w):
-            # the reference resizes a smaller disparity map to the view (DF.cpp:239-247, 268-277);
-            # that path is not built yet
-            raise AdfError(_lib.ADF_ESIZE, "disparity map and view sizes differ (resize path not built)")
+        if gv.n != dl.n:
+            raise AdfError(_lib.ADF_ESIZE, "batch sizes of disparity maps and views differ")
+        # a disparity map of another resolution is resized to the view (DF.cpp:224-227, 239-247, 268-277)
         dr = None
         if disparity_map_right is not None and getattr(disparity_map_right, "size", 1) != 0:
             dr = _Image(disparity_map_right, np.int16, "disparity_map_right", batched)
@@ -221,22 +220,22 @@ class DisparityWLSFilter(DisparityFilter):
         if len({im.device for im in imgs}) != 1:
             raise AdfError(_lib.ADF_EBADARG, "inputs must all be numpy arrays or all be CUDA tensors")
         if filtered_disparity_map is None:
-            filtered_disparity_map = _out_like(dl, batched, np.int16)
+            filtered_disparity_map = _out_like(gv, batched, np.int16)
         out = _Image(filtered_disparity_map, np.int16, "filtered_disparity_map", batched)
-        if (out.n, out.h, out.w) != (dl.n, dl.h, dl.w) or out.device != dl.device:
+        if (out.n, out.h, out.w) != (gv.n, gv.h, gv.w) or out.device != dl.device:               # DF.cpp:252,282
             raise AdfError(_lib.ADF_ESIZE, "filtered_disparity_map has the wrong size or placement")
         roi = _as_rect(ROI)
         args = [self._h, dl.n,
-                C.c_void_p(dl.ptr), dl.stride, dl.pair_stride,
-                C.c_void_p(gv.ptr), gv.stride, gv.pair_stride, gv.c, dl.w, dl.h,
+                C.c_void_p(dl.ptr), dl.stride, dl.pair_stride, dl.w, dl.h,
+                C.c_void_p(gv.ptr), gv.stride, gv.pair_stride, gv.c, gv.w, gv.h,
                 C.c_void_p(out.ptr), out.stride, out.pair_stride,
                 C.c_void_p(dr.ptr) if dr else None, dr.stride if dr else 0, dr.pair_stride if dr else 0,
                 C.byref(roi) if roi is not None else None]
         if dl.device:
-            _lib.check(_lib.lib().adf_wls_filter_device(*args, _stream_of(dl)))
+            _lib.check(_lib.lib().adf_wls_filter_scaled_device(*args, _stream_of(dl)))
         else:
-            _lib.check(_lib.lib().adf_wls_filter_host(*args))
-        self._last = (batched, dl.device, dl)
+            _lib.check(_lib.lib().adf_wls_filter_scaled_host(*args))
+        self._last = (batched, dl.device, gv)
         return filtered_disparity_map
 
     def getConfidenceMap(self, pair=None):

@@ -122,6 +122,29 @@ int adf_wls_filter_host(adf_wls_t* h, int n_pairs,
                         const int16_t* disp_right, ptrdiff_t disp_right_stride, ptrdiff_t disp_right_pair_stride,
                         const adf_rect* roi);
 
+/* The same call with disparity maps of a LOWER resolution than the view (DF.hpp:59-61: "Disparity map can
+ * have any resolution, it will be automatically resized to fit left_view resolution"; DF.cpp:224-227,
+ * 239-247, 268-277): maps are disp_W x disp_H, view and output W x H; the confidence map is computed at
+ * the maps' resolution with LRC_thresh and the roll-off scaled by resize_factor = disp_W/W, then both are
+ * resized (bilinear) and the disparity multiplied by W/disp_W.  roi is in disparity-map coordinates.
+ * With disp_W == W and disp_H == H this is adf_wls_filter_*. */
+int adf_wls_filter_scaled_device(adf_wls_t* h, int n_pairs,
+                                 const int16_t* disp_left, ptrdiff_t disp_left_stride, ptrdiff_t disp_left_pair_stride,
+                                 int disp_W, int disp_H,
+                                 const uint8_t* left_view, ptrdiff_t view_stride, ptrdiff_t view_pair_stride,
+                                 int view_channels, int W, int H,
+                                 int16_t* out, ptrdiff_t out_stride, ptrdiff_t out_pair_stride,
+                                 const int16_t* disp_right, ptrdiff_t disp_right_stride, ptrdiff_t disp_right_pair_stride,
+                                 const adf_rect* roi, void* stream);
+int adf_wls_filter_scaled_host(adf_wls_t* h, int n_pairs,
+                               const int16_t* disp_left, ptrdiff_t disp_left_stride, ptrdiff_t disp_left_pair_stride,
+                               int disp_W, int disp_H,
+                               const uint8_t* left_view, ptrdiff_t view_stride, ptrdiff_t view_pair_stride,
+                               int view_channels, int W, int H,
+                               int16_t* out, ptrdiff_t out_stride, ptrdiff_t out_pair_stride,
+                               const int16_t* disp_right, ptrdiff_t disp_right_stride, ptrdiff_t disp_right_pair_stride,
+                               const adf_rect* roi);
+
 /* getConfidenceMap() (DF.hpp:117, DF.cpp:138): CV_32FC1, W x H, values in [0,255],
  * zero outside the ROI, of pair `pair` of the last filter call.  Valid until the
  * next filter call on the handle. */

@@ -132,8 +132,6 @@ public:
             throw Exception(ADF_EBADARG, "disparity_map_left must be a non-empty CV_16SC1 image");
         if (view.empty() || mat_depth(view) != D8U || (mat_channels(view) != 1 && mat_channels(view) != 3)) // :222
             throw Exception(ADF_EBADARG, "left_view must be CV_8UC1 or CV_8UC3");
-        if (dl.rows != view.rows || dl.cols != view.cols)
-            throw Exception(ADF_ESIZE, "disparity map and view sizes differ (resize path not built)");
         const bool have_r = !dr.empty();
         if (use_confidence_) {                                                 // DF.cpp:262-264
             if (!have_r || mat_depth(dr) != D16S || mat_channels(dr) != 1)
@@ -141,14 +139,15 @@ public:
             if (dr.rows != dl.rows || dr.cols != dl.cols)
                 throw Exception(ADF_ESIZE, "left and right disparity maps differ in size");
         }
-        mat_create(out, dl.rows, dl.cols, D16S, 1);                            // DF.cpp:252,282
+        mat_create(out, view.rows, view.cols, D16S, 1);                        // DF.cpp:252,282 (view-sized)
         adf_rect roi{ROI.x, ROI.y, ROI.width, ROI.height};
-        check(adf_wls_filter_host(h_, 1, reinterpret_cast<const int16_t*>(dl.data), mat_step(dl), 0,
-                                  view.data, mat_step(view), 0, mat_channels(view), dl.cols, dl.rows,
+        // a lower-resolution disparity map is resized to the view inside the call (DF.cpp:239-247,268-277)
+        check(adf_wls_filter_scaled_host(h_, 1, reinterpret_cast<const int16_t*>(dl.data), mat_step(dl), 0, dl.cols, dl.rows,
+                                  view.data, mat_step(view), 0, mat_channels(view), view.cols, view.rows,
                                   reinterpret_cast<int16_t*>(out.data), mat_step(out), 0,
                                   have_r ? reinterpret_cast<const int16_t*>(dr.data) : nullptr, have_r ? mat_step(dr) : 0, 0,
                                   ROI.area() != 0 ? &roi : nullptr));
-        last_rows_ = dl.rows; last_cols_ = dl.cols;
+        last_rows_ = view.rows; last_cols_ = view.cols;
     }
     double getLambda() override { double v; check(adf_wls_get_lambda(h_, &v)); return v; }
     void setLambda(double v) override { check(adf_wls_set_lambda(h_, v)); }

@@ -70,6 +70,10 @@ def lib():
         L.adf_oracle_bad_pixel_percent.argtypes = [vp, vp, i, i, i, i, i, i, i]
         L.adf_oracle_bad_pixel_percent.restype = d
         L.adf_oracle_disparity_vis.argtypes = [vp, vp, i, i, d]
+        L.adf_oracle_resize_linear_16s.argtypes = [vp, i, i, vp, i, i, f]
+        L.adf_oracle_resize_linear_32f.argtypes = [vp, i, i, vp, i, i]
+        L.adf_oracle_wls_filter_scaled.argtypes = [C.POINTER(Params), vp, vp, i, i, vp, i, i, i, i, i, i, i, vp, vp]
+        L.adf_oracle_wls_filter_scaled.restype = i
         L.adf_oracle_sat16.argtypes = [f]
         L.adf_oracle_sat16.restype = C.c_int16
         _lib = L
@@ -214,3 +218,32 @@ def disparity_vis(src, scale=1.0):
     out = np.empty(s.shape, np.uint8)
     lib().adf_oracle_disparity_vis(_p(s), _p(out), s.shape[1], s.shape[0], float(scale))
     return out
+
+
+def resize_linear(src, dsize, post_scale=1.0):
+    """cv::resize(src, dsize=(w, h), INTER_LINEAR) restated for int16 / float32 single-channel images."""
+    a = np.ascontiguousarray(src)
+    sh, sw = a.shape
+    dw, dh = dsize
+    out = np.empty((dh, dw), a.dtype)
+    if a.dtype == np.int16:
+        lib().adf_oracle_resize_linear_16s(_p(a), sw, sh, _p(out), dw, dh, float(post_scale))
+    else:
+        lib().adf_oracle_resize_linear_32f(_p(np.ascontiguousarray(a, np.float32)), sw, sh, _p(out), dw, dh)
+    return out
+
+
+def wls_filter_scaled(dispL, guide, dispR, roi, params=None):
+    """DisparityWLSFilter::filter with low-resolution disparity maps (ROI in their coordinates)."""
+    p = params if params is not None else default_params()
+    dl = np.ascontiguousarray(dispL, np.int16)
+    dH, dW = dl.shape
+    g, ch, W, H, _ = _guide(guide)
+    dr = None if dispR is None else np.ascontiguousarray(dispR, np.int16)
+    out = np.empty((H, W), np.int16)
+    conf = np.empty((H, W), np.float32)
+    rc = lib().adf_oracle_wls_filter_scaled(C.byref(p), _p(dl), None if dr is None else _p(dr), dW, dH, _p(g), ch, W, H,
+                                            roi[0], roi[1], roi[2], roi[3], _p(out), _p(conf))
+    if rc:
+        raise ValueError("adf_oracle_wls_filter_scaled rc=%d" % rc)
+    return out, conf

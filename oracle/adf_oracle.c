@@ -603,3 +603,139 @@ void adf_oracle_disparity_vis(const int16_t* src, uint8_t* dst, int W, int H, do
         }
     }
 }
+
+/* ------------------------------------------------------------------ */
+/* N1: down-scaled disparity path, DF.cpp:224-227, :239-247, :268-277   */
+/* ------------------------------------------------------------------ */
+/* cv::resize(..., INTER_LINEAR) for CV_16SC1 / CV_32FC1 as OpenCV 3.x's imgwarp.cpp computes it
+ * (un-vendored, version unpinned => "parity unpinned"; restated from the published algorithm):
+ *   fx = (float)((dx+0.5)*scale_x - 0.5), sx = floor(fx), fx -= sx; sx<0 -> (0, fx=0);
+ *   sx >= sw-1 -> (sw-1, fx=0); alpha = (1.f-fx, fx) as float; rows likewise but with CLAMPED
+ *   source rows instead of zeroed weights; horizontal pass S[sx]*a0 + S[sx+1]*a1 in float (exact
+ *   S[sx] where sx+1 would leave the row), vertical pass r0*b0 + r1*b1 in float, then
+ *   saturate_cast for CV_16S.  No fused multiply-add. */
+typedef struct { int s0; float a0, a1; int interp; } lin_tab;
+
+static void lin_table(int ssize, int dsize, lin_tab* t)
+{
+    double scale = (double)ssize / dsize;
+    for (int d = 0; d < dsize; d++) {
+        float f = (float)((d + 0.5) * scale - 0.5);
+        int s = (int)floorf(f);
+        f -= (float)s;
+        if (s < 0) { f = 0; s = 0; }
+        if (s >= ssize - 1) { f = 0; s = ssize - 1; }
+        t[d].s0 = s; t[d].a0 = 1.f - f; t[d].a1 = f;
+        t[d].interp = (s + 1 < ssize);                  /* dx < xmax */
+    }
+}
+
+static void resize_linear_f(const void* src, int is16, int sw, int sh, ptrdiff_t sstride,
+                            void* dst, int dw, int dh, ptrdiff_t dstride, float post_scale)
+{
+    lin_tab* tx = (lin_tab*)malloc(sizeof(lin_tab) * (size_t)dw);
+    lin_table(sw, dw, tx);
+    double scale_y = (double)sh / dh;
+    float* r0 = (float*)malloc(sizeof(float) * (size_t)dw);
+    float* r1 = (float*)malloc(sizeof(float) * (size_t)dw);
+    for (int dy = 0; dy < dh; dy++) {
+        float fy = (float)((dy + 0.5) * scale_y - 0.5);
+        int sy = (int)floorf(fy);
+        fy -= (float)sy;
+        const float b0 = 1.f - fy, b1 = fy;
+        int y0 = sy < 0 ? 0 : sy > sh - 1 ? sh - 1 : sy;
+        int y1 = sy + 1 < 0 ? 0 : sy + 1 > sh - 1 ? sh - 1 : sy + 1;
+        for (int k = 0; k < 2; k++) {
+            const char* row = (const char*)src + (ptrdiff_t)(k ? y1 : y0) * sstride;
+            float* r = k ? r1 : r0;
+            for (int dx = 0; dx < dw; dx++) {
+                const int s = tx[dx].s0;
+                const float v0 = is16 ? (float)((const int16_t*)row)[s] : ((const float*)row)[s];
+                if (tx[dx].interp) {
+                    const float v1 = is16 ? (float)((const int16_t*)row)[s + 1] : ((const float*)row)[s + 1];
+                    r[dx] = v0 * tx[dx].a0 + v1 * tx[dx].a1;
+                } else
+                    r[dx] = v0;
+            }
+        }
+        char* drow = (char*)dst + (ptrdiff_t)dy * dstride;
+        for (int dx = 0; dx < dw; dx++) {
+            const float v = r0[dx] * b0 + r1[dx] * b1;
+            if (is16) {
+                int16_t q = adf_oracle_sat16(v);
+                /* disp_full_size*x_ratio (DF.cpp:244,273): convertTo with a float scale, saturating */
+                ((int16_t*)drow)[dx] = post_scale == 1.0f ? q : adf_oracle_sat16((float)q * post_scale + 0.0f);
+            } else
+                ((float*)drow)[dx] = v;
+        }
+    }
+    free(r0); free(r1); free(tx);
+}
+
+void adf_oracle_resize_linear_16s(const int16_t* src, int sw, int sh, int16_t* dst, int dw, int dh, float post_scale)
+{
+    resize_linear_f(src, 1, sw, sh, (ptrdiff_t)sw * 2, dst, dw, dh, (ptrdiff_t)dw * 2, post_scale);
+}
+
+void adf_oracle_resize_linear_32f(const float* src, int sw, int sh, float* dst, int dw, int dh)
+{
+    resize_linear_f(src, 0, sw, sh, (ptrdiff_t)sw * 4, dst, dw, dh, (ptrdiff_t)dw * 4, 1.0f);
+}
+
+/* DF.cpp:219-298 with disparity maps (dW x dH) smaller than the view (W x H).  ROI is given in
+ * DISPARITY-MAP coordinates (DF.cpp:228-233); conf_out is the view-sized confidence map. */
+int adf_oracle_wls_filter_scaled(const adf_oracle_params* p, const int16_t* dispL, const int16_t* dispR,
+                                 int dW, int dH, const uint8_t* guide, int gch, int W, int H,
+                                 int rx, int ry, int rw, int rh, int16_t* out, float* conf_out)
+{
+    if (!p || !dispL || !guide || !out || dW <= 0 || dH <= 0 || W <= 0 || H <= 0) return 1;
+    if (rw <= 0 || rh <= 0 || rx < 0 || ry < 0 || rx + rw > dW || ry + rh > dH) return 2;
+    const float resize_factor = dW / (float)W;                             /* DF.cpp:225 */
+    const float x_ratio = W / (float)dW, y_ratio = H / (float)dH;          /* DF.cpp:241-242,270-271 */
+    const int hx = (int)(rx * x_ratio), hy = (int)(ry * y_ratio);           /* DF.cpp:245-246,275-276 */
+    const int hw = (int)(rw * x_ratio), hh = (int)(rh * y_ratio);
+    if (hw <= 0 || hh <= 0 || hx + hw > W || hy + hh > H) return 2;
+    int16_t* dhi = (int16_t*)malloc(sizeof(int16_t) * (size_t)W * H);
+    float* chi = conf_out ? conf_out : (float*)malloc(sizeof(float) * (size_t)W * H);
+    if (!dhi || !chi) { free(dhi); if (!conf_out) free(chi); return 4; }
+    adf_oracle_resize_linear_16s(dispL, dW, dH, dhi, W, H, x_ratio);      /* DF.cpp:243-244,272-273 */
+    const size_t P = (size_t)hw * hh;
+    const uint8_t* groi = guide + ((size_t)hy * W + hx) * gch;
+    for (size_t k = 0; k < (size_t)W * H; k++) out[k] = (int16_t)-16;      /* DF.cpp:254,284 */
+    int rc;
+    if (!p->use_confidence) {
+        int16_t* tmp = (int16_t*)malloc(sizeof(int16_t) * P);
+        for (int i = 0; i < hh; i++) memcpy(tmp + (size_t)i * hw, dhi + (size_t)(hy + i) * W + hx, sizeof(int16_t) * (size_t)hw);
+        rc = adf_oracle_fgs_filter(groi, (ptrdiff_t)W * gch, gch, hw, hh, tmp, tmp, ADF_DEPTH_16S, 1, p->lambda,
+                                   p->sigma_color, p->lambda_attenuation, p->num_iter, p->order, p->threads);
+        if (rc == 0)
+            for (int i = 0; i < hh; i++) memcpy(out + (size_t)(hy + i) * W + hx, tmp + (size_t)i * hw, sizeof(int16_t) * (size_t)hw);
+        free(tmp);
+        if (conf_out) memset(conf_out, 0, sizeof(float) * (size_t)W * H);
+    } else {
+        if (!dispR) { free(dhi); if (!conf_out) free(chi); return 1; }
+        float* clo = (float*)malloc(sizeof(float) * (size_t)dW * dH);
+        float* planes = (float*)malloc(sizeof(float) * 2 * P);
+        adf_oracle_confidence(dispL, (ptrdiff_t)dW * 2, dispR, (ptrdiff_t)dW * 2, dW, dH, rx, ry, rw, rh, p->disc_radius,
+                              p->lrc_thresh, resize_factor, clo, p->threads);          /* DF.cpp:265 */
+        adf_oracle_resize_linear_32f(clo, dW, dH, chi, W, H);                         /* DF.cpp:274 */
+        for (int i = 0; i < hh; i++)
+            for (int j = 0; j < hw; j++) {
+                const float c = chi[(size_t)(hy + i) * W + hx + j];
+                planes[(size_t)i * hw + j] = c * (float)dhi[(size_t)(hy + i) * W + hx + j];
+                planes[P + (size_t)i * hw + j] = c;
+            }
+        rc = adf_oracle_fgs_planes(groi, (ptrdiff_t)W * gch, gch, hw, hh, planes, 2, p->lambda, p->sigma_color,
+                                   p->lambda_attenuation, p->num_iter, p->order, p->threads);
+        if (rc == 0)
+            for (int i = 0; i < hh; i++)
+                for (int j = 0; j < hw; j++) {
+                    const float rcp = 1.0f / (planes[P + (size_t)i * hw + j] + ADF_EPS);
+                    out[(size_t)(hy + i) * W + hx + j] = adf_oracle_sat16(planes[(size_t)i * hw + j] * rcp);
+                }
+        free(clo); free(planes);
+    }
+    free(dhi);
+    if (!conf_out) free(chi);
+    return rc;
+}

@@ -124,6 +124,16 @@ double adf_oracle_compute_mse(const int16_t* gt, const int16_t* src, int W, int 
 double adf_oracle_bad_pixel_percent(const int16_t* gt, const int16_t* src, int W, int H, int rx, int ry, int rw, int rh, int thresh);
 void adf_oracle_disparity_vis(const int16_t* src, uint8_t* dst, int W, int H, double scale);
 
+/* cv::resize(INTER_LINEAR) restated for CV_16SC1 (optionally followed by the saturating *x_ratio of
+ * DF.cpp:244,273) and CV_32FC1; dense rows.  OpenCV-imgproc boundary: parity unpinned. */
+void adf_oracle_resize_linear_16s(const int16_t* src, int sw, int sh, int16_t* dst, int dw, int dh, float post_scale);
+void adf_oracle_resize_linear_32f(const float* src, int sw, int sh, float* dst, int dw, int dh);
+/* DF.cpp:219-298 with disparity maps (dW x dH, dense) smaller than the view (W x H, dense); ROI in
+ * disparity-map coordinates; conf_out: nullable view-sized confidence map. */
+int adf_oracle_wls_filter_scaled(const adf_oracle_params* p, const int16_t* dispL, const int16_t* dispR,
+                                 int dW, int dH, const uint8_t* guide, int gch, int W, int H,
+                                 int rx, int ry, int rw, int rh, int16_t* out, float* conf_out);
+
 /* saturate_cast<short>(float) = cvRound + clamp (DF.cpp:296, FGS.cpp:216);
  * exported so tests can probe the rounding convention directly. */
 int16_t adf_oracle_sat16(float v);
