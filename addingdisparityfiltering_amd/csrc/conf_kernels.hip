@@ -109,7 +109,18 @@ __global__ void __launch_bounds__(NT) discontinuity_kernel(DiscArgs a)
 // ring slots are compile-time).  All sums are exact 32-bit integers: the sum of squares is kept as
 // sum(d^2 >> 16) and sum(d^2 & 0xffff) and recombined in double.
 // ---------------------------------------------------------------------------------------
-constexpr int DC_ROWS = 128; // output rows per block
+// Output rows per block of the column-walking kernels: gridDim.y row blocks share the ROI's rows.
+// The launchers use 128 rows per block for big batches (halo rows and the LUT / prefetch ramp are
+// amortised) and fewer when the whole launch would otherwise be too few blocks to fill 256 CUs
+// (single-image latency).
+#define DC_ROWS ((rows_total + (int)gridDim.y - 1) / (int)gridDim.y)
+
+inline int row_blocks(int rows, int blocks_xz)
+{
+    int rpb = 128;
+    while (rpb > 16 && ((rows + rpb - 1) / rpb) * blocks_xz < 2048) rpb >>= 1;
+    return (rows + rpb - 1) / rpb;
+}
 
 // Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains every outstanding
 // global load (s_waitcnt vmcnt(0)), which would serialise the row prefetch and the LRC gathers of the
@@ -126,6 +137,7 @@ __global__ void __launch_bounds__(NT) discontinuity_col_kernel(DiscArgs a)
     constexpr int OUTW = NT - 2 * RT;
     __shared__ int rowbuf[2][NT];
     const int tid = threadIdx.x;
+    const int rows_total = a.rh;
     const int view = a.only_view >= 0 ? a.only_view : (int)(blockIdx.z & 1);
     const size_t pz = a.only_view >= 0 ? blockIdx.z : (blockIdx.z >> 1);
     const int x_out0 = blockIdx.x * OUTW, y_out0 = blockIdx.y * DC_ROWS;
@@ -204,6 +216,7 @@ __global__ void __launch_bounds__(NT) conf_left_kernel(ConfLeftArgs a)
     __shared__ int rowbuf[2][NT];
     const Geom& g = a.g;
     const int tid = threadIdx.x;
+    const int rows_total = g.rh;
     const size_t pz = blockIdx.z;
     const int x_out0 = blockIdx.x * OUTW, y_out0 = blockIdx.y * DC_ROWS;
     const char* baseL = reinterpret_cast<const char*>(a.dL) + (ptrdiff_t)pz * a.psL;
@@ -472,10 +485,11 @@ hipError_t launch_discontinuity(const DiscArgs& a, int n_pairs, hipStream_t st)
     if (a.rw <= 0 || a.rh <= 0 || n_pairs <= 0) return hipSuccess;
     if (a.radius < 0 || a.radius > MAX_RADIUS) return hipErrorInvalidValue;
     if (a.radius <= 8) {
-        dim3 grid(1, (a.rh + DC_ROWS - 1) / DC_ROWS, (a.only_view >= 0 ? 1 : 2) * n_pairs);
+        dim3 grid(1, 1, (a.only_view >= 0 ? 1 : 2) * n_pairs);
 #define ADF_DC(RR)                                                                             \
     case RR:                                                                                   \
         grid.x = (a.rw + (NT - 2 * RR) - 1) / (NT - 2 * RR);                                   \
+        grid.y = row_blocks(a.rh, grid.x * grid.z);                                            \
         hipLaunchKernelGGL(discontinuity_col_kernel<RR>, grid, dim3(NT), 0, st, a);            \
         break;
         switch (a.radius) {
@@ -504,10 +518,11 @@ hipError_t launch_conf_left(const ConfLeftArgs& a, int n_pairs, hipStream_t st)
 {
     if (a.radius < 0 || a.radius > 8) return hipErrorInvalidValue;
     const bool wu = a.U0 != nullptr;
-    dim3 grid(1, (a.g.rh + DC_ROWS - 1) / DC_ROWS, n_pairs);
+    dim3 grid(1, 1, n_pairs);
 #define ADF_CL(RR)                                                                             \
     case RR:                                                                                   \
         grid.x = (a.g.rw + (NT - 2 * RR) - 1) / (NT - 2 * RR);                                 \
+        grid.y = row_blocks(a.g.rh, grid.x * grid.z);                                          \
         if (wu) hipLaunchKernelGGL((conf_left_kernel<RR, true>), grid, dim3(NT), 0, st, a);    \
         else hipLaunchKernelGGL((conf_left_kernel<RR, false>), grid, dim3(NT), 0, st, a);      \
         break;

@@ -122,7 +122,8 @@ __global__ void __launch_bounds__(NT) weights_kernel(WeightArgs a)
 // costs CH + CH LDS byte reads, two table look-ups (head of the LUT cached in LDS once per block) and
 // two coalesced 1 KiB stores: Chor of this row and Cvert of the previous one.
 // ---------------------------------------------------------------------------------------
-constexpr int WS_ROWS = 128;
+// rows per block: gridDim.y row blocks share the ROI's rows (see conf_kernels.hip, row_blocks)
+#define WS_ROWS ((g.rh + (int)gridDim.y - 1) / (int)gridDim.y)
 constexpr int WS_U = 16;
 
 template <int CH>
@@ -204,7 +205,12 @@ hipError_t launch_weights(const WeightArgs& a, int n_pairs, hipStream_t st)
 {
     if (a.cvert_orient != ORIENT_N) return hipErrorInvalidValue;
     if (a.chor_orient == ORIENT_N) {   // wave solver: streaming kernel
-        dim3 sgrid((a.g.rw + NT - 1) / NT, (a.g.rh + WS_ROWS - 1) / WS_ROWS, n_pairs);
+        dim3 sgrid((a.g.rw + NT - 1) / NT, 1, n_pairs);
+        {
+            int rpb = 128;
+            while (rpb > 16 && ((a.g.rh + rpb - 1) / rpb) * (int)(sgrid.x * sgrid.z) < 2048) rpb >>= 1;
+            sgrid.y = (a.g.rh + rpb - 1) / rpb;
+        }
         if (a.ch == 1) hipLaunchKernelGGL(weights_stream_kernel<1>, sgrid, dim3(NT), 0, st, a);
         else if (a.ch == 3) hipLaunchKernelGGL(weights_stream_kernel<3>, sgrid, dim3(NT), 0, st, a);
         else return hipErrorInvalidValue;
