@@ -113,6 +113,13 @@ __global__ void __launch_bounds__(NT) discontinuity_kernel(DiscArgs a)
 // The launchers use 128 rows per block for big batches (halo rows and the LUT / prefetch ramp are
 // amortised) and fewer when the whole launch would otherwise be too few blocks to fill 256 CUs
 // (single-image latency).
+#ifndef ADF_CONF_GROUP
+#define ADF_CONF_GROUP 8 // rows per prefetch / gather group of the column-walking kernels (measured: 8 beats 16 and 32:
+                         // fewer registers -> more resident waves matters more than prefetch depth)
+#endif
+#ifndef ADF_LRC_GROUP
+#define ADF_LRC_GROUP 4  // same for the fused left-view kernel (it also carries the gathered dR / cR per row)
+#endif
 #define DC_ROWS ((rows_total + (int)gridDim.y - 1) / (int)gridDim.y)
 
 inline int row_blocks(int rows, int blocks_xz)
@@ -157,7 +164,7 @@ __global__ void __launch_bounds__(NT) discontinuity_col_kernel(DiscArgs a)
 
     // rows are consumed in groups of U (a multiple of the window height K, so that ring slots stay
     // compile-time) and the next group's U loads are in flight while the current group is reduced
-    constexpr int U = K * ((16 + K - 1) / K);
+    constexpr int U = K * ((ADF_CONF_GROUP + K - 1) / K);
     int r1[K], rlo[K], rhi[K];
     int S1 = 0, Slo = 0, Shi = 0;
     int nxt[U];
@@ -211,7 +218,7 @@ __global__ void __launch_bounds__(NT) conf_left_kernel(ConfLeftArgs a)
 {
     constexpr int K = 2 * RT + 1;
     constexpr int OUTW = NT - 2 * RT;
-    constexpr int U = K * ((16 + K - 1) / K);
+    constexpr int U = K * ((ADF_LRC_GROUP + K - 1) / K);
     constexpr int CR = RT > 0 ? RT : 1;
     __shared__ int rowbuf[2][NT];
     const Geom& g = a.g;

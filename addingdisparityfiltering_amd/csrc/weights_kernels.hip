@@ -124,7 +124,10 @@ __global__ void __launch_bounds__(NT) weights_kernel(WeightArgs a)
 // ---------------------------------------------------------------------------------------
 // rows per block: gridDim.y row blocks share the ROI's rows (see conf_kernels.hip, row_blocks)
 #define WS_ROWS ((g.rh + (int)gridDim.y - 1) / (int)gridDim.y)
-constexpr int WS_U = 16;
+#ifndef ADF_WS_GROUP
+#define ADF_WS_GROUP 16
+#endif
+constexpr int WS_U = ADF_WS_GROUP;
 
 template <int CH>
 __global__ void __launch_bounds__(NT) weights_stream_kernel(WeightArgs a)
