@@ -155,3 +155,34 @@ def test_switching_solvers_on_one_handle(adf, oracle):
     assert d2.max() <= MAX_DIF and d2.mean() <= MAX_MEAN_DIF
     f.setSolver(adf.SOLVER_EXACT)
     assert np.array_equal(f.filter(dl, view, None, dr, roi), exp)
+
+
+def test_filter_call_is_graph_capturable(adf, oracle):
+    """once the workspace exists the device-pointer call does no host
+    synchronisation or allocation, so a caller can capture it into a hipGraph and replay it."""
+    import torch
+
+    view, dl, dr, roi, radius = synthetic.make_config_example(1)
+    dev = torch.device("cuda:0")
+    tv, tl, tr = (torch.from_numpy(a).to(dev) for a in (view, dl, dr))
+    out = torch.empty(dl.shape, dtype=torch.int16, device=dev)
+    f = adf.createDisparityWLSFilterGeneric(True)
+    f.setSolver(adf.SOLVER_WAVE); f.setSigmaColor(1.5); f.setDepthDiscontinuityRadius(radius)
+    f.filter(tl, tv, out, tr, roi)                                  # first call sizes the workspace
+    torch.cuda.synchronize()
+    eager = out.clone()
+    s = torch.cuda.Stream()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.stream(s):
+        s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.graph(g, stream=s):
+            f.filter(tl, tv, out, tr, roi)
+    out.zero_()
+    tl2 = torch.from_numpy(np.ascontiguousarray(dl + 16)).to(dev)   # new input values, same buffers
+    tl.copy_(tl2)
+    g.replay()
+    torch.cuda.synchronize()
+    exp, _ = oracle.wls_filter(dl + 16, view, dr, roi, oracle.default_params(sigma_color=1.5, disc_radius=radius, threads=8))
+    d = np.abs(out.cpu().numpy().astype(np.int64) - exp)
+    assert d.max() <= MAX_DIF and d.mean() <= MAX_MEAN_DIF
+    assert not torch.equal(out, eager)
