@@ -54,9 +54,12 @@ __global__ void __launch_bounds__(64, 2) wave_hpass_kernel(WavePassArgs a)
                     t0[k] = make_float4(cf.x * (float)dd.x, cf.y * (float)dd.y, cf.z * (float)dd.z, cf.w * (float)dd.w);
                 }
             } else if (idx < nvec) {
-                tC[k] = sC[idx];
-                t0[k] = s0[idx];
-                if (R > 1) t1[k] = s1[idx];
+                // non-temporal: every byte of a row pass is used exactly once (measured -5 % on the pass;
+                // the vertical pass must NOT do this: its paired strips rely on L2 to share 128-byte lines)
+                { typedef float v4f __attribute__((ext_vector_type(4)));
+                  v4f a = __builtin_nontemporal_load(reinterpret_cast<const v4f*>(sC) + idx); tC[k] = make_float4(a.x, a.y, a.z, a.w);
+                  a = __builtin_nontemporal_load(reinterpret_cast<const v4f*>(s0) + idx); t0[k] = make_float4(a.x, a.y, a.z, a.w);
+                  if (R > 1) { a = __builtin_nontemporal_load(reinterpret_cast<const v4f*>(s1) + idx); t1[k] = make_float4(a.x, a.y, a.z, a.w); } }
             }
         }
     }
@@ -107,7 +110,8 @@ __global__ void __launch_bounds__(64, 2) wave_hpass_kernel(WavePassArgs a)
 #pragma unroll
         for (int k = 0; k < M / 4; k++) {
             const int idx = 64 * k + lane;
-            if (idx < nvec) d4[idx] = stage[idx];
+            if (idx < nvec) { typedef float v4f __attribute__((ext_vector_type(4))); const float4 q = stage[idx]; v4f a = {q.x, q.y, q.z, q.w};
+                              __builtin_nontemporal_store(a, reinterpret_cast<v4f*>(d4) + idx); }
         }
         __syncthreads();
     };
