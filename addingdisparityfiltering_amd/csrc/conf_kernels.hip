@@ -21,6 +21,8 @@ namespace adf {
 
 namespace {
 
+// streaming outputs are written once and read by a later kernel after gigabytes of other traffic
+#define ADF_ST(p, v) __builtin_nontemporal_store((v), (p))
 constexpr int TX = 64; // tile width  (one wavefront wide: 128-byte int16 rows, 256-byte float rows)
 constexpr int TY = 32; // tile height
 constexpr int NT = 256;
@@ -200,7 +202,7 @@ __global__ void __launch_bounds__(NT) discontinuity_col_kernel(DiscArgs a)
                     const float sq = (float)(((double)Shi * 65536.0 + (double)Slo) * scale);
                     const float variance = sq - mean * mean;      // DF.cpp:369
                     const float v = 1.0f - a.roll_off * variance; // DF.cpp:370
-                    dst[(size_t)oy * a.W] = v < 0.0f ? 0.0f : v;
+                    ADF_ST(&dst[(size_t)oy * a.W], v < 0.0f ? 0.0f : v);
                 }
             }
         }
@@ -312,7 +314,7 @@ __global__ void __launch_bounds__(NT) conf_left_kernel(ConfLeftArgs a)
                         else c = 0.0f;                                   // DF.cpp:337
                     }
                     c = 255.0f * c;                               // DF.cpp:209
-                    conf[(size_t)i_abs * g.W + j_abs] = c;
+                    ADF_ST(&conf[(size_t)i_abs * g.W + j_abs], c);
                     if (WRITE_U) {
                         const size_t o = pz * g.plane + (size_t)oy * g.pw + gx_out;
                         a.U0[o] = c * (float)d;                   // DF.cpp:289-290

@@ -15,6 +15,8 @@ namespace adf {
 
 namespace {
 
+// streaming outputs are written once and read by a later kernel after gigabytes of other traffic
+#define ADF_ST(p, v) __builtin_nontemporal_store((v), (p))
 constexpr int TX = 64, TY = 32, NT = 256;
 constexpr int LUT_HEAD = 2048;
 
@@ -193,9 +195,9 @@ __global__ void __launch_bounds__(NT) weights_stream_kernel(WeightArgs a)
                 const int i = y0 + n;                          // ROI row of this input row (when n < nrows-1)
                 if (okx) {
                     if (n < nrows - 1)                         // Chor of this row, FGS.cpp:607-614
-                        chor[(size_t)i * g.pw + j] = (j == g.rw - 1) ? 0.0f : lookup(hidx);
+                        ADF_ST(&chor[(size_t)i * g.pw + j], (j == g.rw - 1) ? 0.0f : lookup(hidx));
                     if (n >= 1)                                // Cvert of the previous row, FGS.cpp:635-660
-                        cvert[(size_t)(i - 1) * g.pw + j] = (i - 1 == g.rh - 1) ? 0.0f : lookup(vidx);
+                        ADF_ST(&cvert[(size_t)(i - 1) * g.pw + j], (i - 1 == g.rh - 1) ? 0.0f : lookup(vidx));
                 }
             }
         }
