@@ -52,14 +52,16 @@ __global__ void __launch_bounds__(VT) wave_vpass_kernel(WavePassArgs a)
     const unsigned voff0 = ((unsigned)r0 * (unsigned)a.pitch + (unsigned)col) * 4u;
 
     float c[2][M], f0[2][M], f1[2][M];
+    const unsigned safe = (unsigned)col * 4u;
     {
         unsigned voff = voff0;
 #pragma unroll
         for (int i = 0; i < M; i++) {
             // rows past the end of the column are identity rows (c = 0, f = 0); their loads are
-            // redirected to the chunk's first row so that no load sits under a divergent branch
+            // redirected to row 0 of the column (always inside the plane, whereas a chunk that lies
+            // entirely past the end starts beyond it) so that no load sits under a divergent branch
             const bool ok = r0 + i < h;
-            const unsigned vo = ok ? voff : voff0;
+            const unsigned vo = ok ? voff : safe;
             const float2 vc = *reinterpret_cast<const float2*>(bC + vo);
             const float2 v0 = *reinterpret_cast<const float2*>(b0 + vo);
             float2 v1 = make_float2(0.f, 0.f);
