@@ -432,12 +432,16 @@ static int wls_filter_impl(adf_wls_t* h, int n_pairs,
     if (!wave) { p.D = take(g.plane); p.F0 = take(g.plane); p.B0 = take(g.plane); }
     float *cL = nullptr, *cR = nullptr;
     if (conf) {
-        p.A1 = take(g.plane);
+        p.A1 = take(g.plane);                     // wave: directly behind A0 (the pair plane spans both)
         if (!wave) { p.F1 = take(g.plane); p.B1 = take(g.plane); }
         cL = take(g.frame); cR = take(g.frame);
     }
-    // exact: the horizontal pass wants the row index fastest (T); wave: everything row-major (N)
+    // exact: the horizontal pass wants the row index fastest (T); wave: row-major (N), except that two
+    // right-hand sides share one interleaved pair plane (A0 and A1 are adjacent: 2*plane floats per
+    // image starting at A0) and Cvert is strip-major -- see fgs_wave_common.h
     const int orient_h = wave ? ORIENT_N : ORIENT_T;
+    const int orient_u2 = wave ? ORIENT_PAIR : ORIENT_T;     // the two right-hand sides of a confidence-mode call
+    const int orient_cv = wave ? ORIENT_STRIP : ORIENT_N;
 
     for (int first = 0; first < n_pairs; first += chunk) {
         const int n = (n_pairs - first < chunk) ? n_pairs - first : chunk;
@@ -453,7 +457,7 @@ static int wls_filter_impl(adf_wls_t* h, int n_pairs,
             ProfScope ps(prof, K_FILL, 2.0 * (F - P), 2.0 * (F - P), st);
             HIP_TRY(launch_outside(oa, n, st));
         }
-        WeightArgs wa{gv, sG, psG, gch, (const float*)h->lut.dev.p, p.CH, p.CV, orient_h, ORIENT_N, g};
+        WeightArgs wa{gv, sG, psG, gch, (const float*)h->lut.dev.p, p.CH, p.CV, orient_h, orient_cv, g};
         {
             ProfScope ps(prof, K_WEIGHTS, (gch + 8.0) * P, (gch + 8.0) * P, st);
             HIP_TRY(launch_weights(wa, n, st));                            // FGS.cpp:163-172
@@ -482,7 +486,7 @@ static int wls_filter_impl(adf_wls_t* h, int n_pairs,
                 fuse.len = g.rw;
                 if (!(wave && wave_hpass_can_fuse(fuse))) {
                     fuse = WavePassArgs{};
-                    PlainPrologueArgs pa{dL, sL, psL, ADF_16S, 1, 0, p.A0, g, orient_h, confp, p.A1};
+                    PlainPrologueArgs pa{dL, sL, psL, ADF_16S, 1, 0, p.A0, g, orient_u2, confp, p.A1};
                     ProfScope ps(prof, K_PROLOGUE, 14.0 * P, 14.0 * P, st);
                     HIP_TRY(launch_plain_prologue(pa, n, st));
                 }
@@ -516,7 +520,7 @@ static int wls_filter_impl(adf_wls_t* h, int n_pairs,
                     ProfScope ps(prof, K_DISC, 4.0 * P, 12.0 * P, st);
                     HIP_TRY(launch_discontinuity(da, n, st));              // DF.cpp:204
                 }
-                LrcArgs la{dL, sL, psL, dRp, sR, psR, cL, cR, confp, o, sO, psO, fill, p.A0, p.A1, g, rrx, thresh, orient_h};
+                LrcArgs la{dL, sL, psL, dRp, sR, psR, cL, cR, confp, o, sO, psO, fill, p.A0, p.A1, g, rrx, thresh, orient_u2};
                 {   // alg: confidence map out (4F) + the two rhs planes (8P); moved adds dL,dR,cL,cR reads
                     ProfScope ps(prof, K_LRC, 4.0 * F + 8.0 * P + 2.0 * (F - P), 4.0 * F + 20.0 * P + 2.0 * (F - P), st);
                     HIP_TRY(launch_lrc_prologue(la, n, st));               // DF.cpp:208-209,288-290
@@ -783,7 +787,8 @@ extern "C" int adf_fgs_create(adf_fgs_t** out, const uint8_t* guide, ptrdiff_t g
     if (e == hipSuccess) {
         float* base = (float*)f->planes.p;
         WeightArgs wa{(const uint8_t*)f->io.p, (ptrdiff_t)w * gch, 0, gch, (const float*)f->lut.dev.p,
-                      base, base + f->g.plane, f->solver == ADF_SOLVER_WAVE ? ORIENT_N : ORIENT_T, ORIENT_N, f->g};
+                      base, base + f->g.plane, f->solver == ADF_SOLVER_WAVE ? ORIENT_N : ORIENT_T,
+                      f->solver == ADF_SOLVER_WAVE ? ORIENT_STRIP : ORIENT_N, f->g};
         e = launch_weights(wa, 1, st);
     }
     if (e == hipSuccess) e = hipStreamSynchronize(st);

@@ -23,8 +23,13 @@ struct Geom {
     size_t frame;       // floats per pair per full-frame plane = W*H
 };
 
-// Destination orientation of a tile-writing kernel.
-enum Orient { ORIENT_N = 0, ORIENT_T = 1 };
+// Destination layout of a plane-writing kernel.
+//   ORIENT_PAIR   (wave solver, two right-hand sides) ONE plane of 2*plane floats per image holding
+//                 both: row-major rows of 2*pw floats, [U0 x16 | U1 x16] per 16-column strip, so that a
+//                 strip row of the column pass is one 128-byte line; the U1 pointer is unused
+//   ORIENT_STRIP  (wave solver, Cvert) strip-major [pw/16][rh][16]
+enum Orient { ORIENT_N = 0, ORIENT_T = 1, ORIENT_PAIR = 2, ORIENT_STRIP = 3 };
+#define ADF_STRIP 16
 
 // What the last sweep of a solve writes (fused epilogues).
 enum Epilogue {
@@ -51,7 +56,7 @@ struct ConfLeftArgs {
     const int16_t* dR; ptrdiff_t sR, psR;
     const float* cR;                      // full-frame, W pitch
     float* conf;                          // full-frame confidence (x255); only ROI pixels are written
-    float* U0; float* U1;                 // row-major ROI planes (may be null: first pass reads conf/dL itself)
+    float* U0; float* U1;                 // ORIENT_PAIR plane at U0 (may be null: first pass reads conf/dL itself); U1 unused
     Geom g; int rrx; int thresh;
     int radius; float roll_off;
 };
@@ -152,6 +157,16 @@ int max_disc_radius();
 
 // Device-side helpers shared by kernels.
 #if defined(__HIPCC__)
+// float index of U0(i, j) inside an ORIENT_PAIR plane of pitch pw (U1 is ADF_STRIP floats further)
+__device__ __forceinline__ size_t pair_index(int i, int j, int pw)
+{
+    return (size_t)i * (size_t)(2 * pw) + (size_t)(((j >> 4) << 5) + (j & 15));
+}
+// float index of C(i, j) inside an ORIENT_STRIP plane of rh rows
+__device__ __forceinline__ size_t strip_index(int i, int j, int rh)
+{
+    return ((size_t)(j >> 4) * (size_t)rh + (size_t)i) * ADF_STRIP + (size_t)(j & 15);
+}
 // saturate_cast<short>(float): cvRound (round-half-even; NaN / out-of-int-range -> INT_MIN) + clamp.
 __device__ __forceinline__ int16_t sat16(float v)
 {

@@ -316,9 +316,9 @@ __global__ void __launch_bounds__(NT) conf_left_kernel(ConfLeftArgs a)
                     c = 255.0f * c;                               // DF.cpp:209
                     ADF_ST(&conf[(size_t)i_abs * g.W + j_abs], c);
                     if (WRITE_U) {
-                        const size_t o = pz * g.plane + (size_t)oy * g.pw + gx_out;
+                        const size_t o = pz * 2 * g.plane + pair_index(oy, gx_out, g.pw);   // ORIENT_PAIR
                         a.U0[o] = c * (float)d;                   // DF.cpp:289-290
-                        a.U1[o] = c;
+                        a.U0[o + ADF_STRIP] = c;
                     }
                 }
             }
@@ -369,8 +369,9 @@ __global__ void __launch_bounds__(NT) lrc_prologue_kernel(LrcArgs a)
     const float* cL = a.cL + pz * g.frame;
     const float* cR = a.cR + pz * g.frame;
     float* conf = a.conf + pz * g.frame;
-    float* U0 = a.U0 ? a.U0 + pz * g.plane : nullptr;   // null: confidence only (down-scaled path)
-    float* U1 = a.U0 ? a.U1 + pz * g.plane : nullptr;
+    const bool pair = a.orient == ORIENT_PAIR;
+    float* U0 = a.U0 ? a.U0 + pz * (pair ? 2 : 1) * g.plane : nullptr;   // null: confidence only (down-scaled path)
+    float* U1 = a.U0 ? (pair ? U0 + ADF_STRIP : a.U1 + pz * g.plane) : nullptr;
     const int j = x0 + tx;
     const int right_end = a.rrx + g.rw;
 
@@ -404,9 +405,9 @@ __global__ void __launch_bounds__(NT) lrc_prologue_kernel(LrcArgs a)
                                            (ptrdiff_t)i * a.sO)[j] = a.fill;
         }
         if (!U0) continue;
-        if (a.orient == ORIENT_N) {
+        if (a.orient != ORIENT_T) {
             if (in_roi) {
-                size_t o = (size_t)(i - g.ry) * g.pw + (j - g.rx);
+                const size_t o = pair ? pair_index(i - g.ry, j - g.rx, g.pw) : (size_t)(i - g.ry) * g.pw + (j - g.rx);
                 U0[o] = u0; U1[o] = c;
             }
         } else {
@@ -439,8 +440,9 @@ __global__ void __launch_bounds__(NT) plain_prologue_kernel(PlainPrologueArgs a)
     const size_t pz = blockIdx.z;
     const char* pL = reinterpret_cast<const char*>(a.src) + (ptrdiff_t)pz * a.pair_stride;
     const float* cf = a.conf ? a.conf + pz * g.frame : nullptr;
-    float* U0 = a.U0 + pz * g.plane;
-    float* U1 = a.conf ? a.U1 + pz * g.plane : nullptr;
+    const bool pair = a.orient == ORIENT_PAIR;          // only with confidence weighting (two right-hand sides)
+    float* U0 = a.U0 + pz * (pair ? 2 : 1) * g.plane;
+    float* U1 = a.conf ? (pair ? U0 + ADF_STRIP : a.U1 + pz * g.plane) : nullptr;
     const int j = x0 + tx;
 #pragma unroll
     for (int kk = 0; kk < TY / 4; kk++) {
@@ -458,8 +460,11 @@ __global__ void __launch_bounds__(NT) plain_prologue_kernel(PlainPrologueArgs a)
                 u0 = u1 * u0;
             }
         }
-        if (a.orient == ORIENT_N) {
-            if (ok) { U0[(size_t)i * g.pw + j] = u0; if (cf) U1[(size_t)i * g.pw + j] = u1; }
+        if (a.orient != ORIENT_T) {
+            if (ok) {
+                const size_t o = pair ? pair_index(i, j, g.pw) : (size_t)i * g.pw + j;
+                U0[o] = u0; if (cf) U1[o] = u1;
+            }
         } else {
             t0[tx * (TY + 1) + ty + 4 * kk] = u0;
             t1[tx * (TY + 1) + ty + 4 * kk] = u1;

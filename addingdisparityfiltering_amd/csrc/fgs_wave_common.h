@@ -23,10 +23,17 @@
 //                    HBM -> (coalesced 16 B/lane) -> LDS -> (chunk per lane) -> registers and back.
 //   vertical pass:   one 512-thread workgroup per strip of 16 columns; thread (chunk, column pair)
 //                    owns M rows of 2 columns; the whole strip (16 x H x 3 floats) lives in the CU's
-//                    register file; neighbour / separator exchange through LDS; each row of the strip
-//                    is a 64-byte segment (the other half of the line is served from L2/MALL to the
-//                    neighbouring strip).
-// All planes are row-major [rh][pw]; nothing is transposed and both passes work in place.
+//                    register file; neighbour / separator exchange through LDS.
+//
+// Data layout (everything is solved in place, nothing is transposed between the passes):
+//   Chor            row-major [rh][pw]
+//   Cvert           strip-major [pw/16][rh][16]: the weights of a vertical strip are one contiguous stream
+//   one right-hand side (R == 1)    row-major [rh][pw]; a strip row is then a 64-byte half line (the
+//                   other half is served from L2/MALL to the neighbouring strip)
+//   two right-hand sides (R == 2)   ONE pair plane [rh][pw/16][U0 x16 | U1 x16] of 2*plane floats per
+//                   image: the row pass still streams whole contiguous rows (it de-interleaves in its
+//                   LDS staging buffer), and a strip row of the column pass is one full 128-byte line
+//                   holding both right-hand sides.  U1 pointers are ignored for R == 2.
 #pragma once
 #include "adf_internal.h"
 

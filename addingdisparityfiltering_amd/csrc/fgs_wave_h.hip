@@ -12,14 +12,22 @@ using namespace wave;
 // FUSED: first pass of a confidence-mode call -- the right-hand sides are formed on the fly from the
 // confidence plane and the left disparity map (U1 = conf, U0 = conf*float(dL), DF.cpp:288-290) instead
 // of being read from planes a prologue kernel would have had to write.
+// (the longest chunk with two right-hand sides does not fit two waves per SIMD without spilling: the
+// pair staging below keeps both right-hand sides and two of the three load batches alive at once)
 template <int M, int R, bool FUSED>
-__global__ void __launch_bounds__(64, 2) wave_hpass_kernel(WavePassArgs a)
+__global__ void __launch_bounds__(64, (M >= 64 && R > 1) ? 1 : 2) wave_hpass_kernel(WavePassArgs a)
 {
     static_assert(M % 4 == 0 && M >= 4, "chunk length must be a multiple of 4");
     __shared__ float4 stage[M * 16];
     const int lane = threadIdx.x;
     const size_t off = (size_t)blockIdx.y * a.plane + (size_t)blockIdx.x * a.pitch;
     const int nvec = a.pitch >> 2;
+    // R == 2: the two right-hand sides live in one pair plane, interleaved per 16 columns
+    // ([U0 x16 | U1 x16] per strip, see fgs_wave_common.h): a row is 2*pitch contiguous floats
+    constexpr bool PAIR = R > 1;
+    const size_t offU = PAIR ? 2 * off : off;
+    const int nvecU = PAIR ? 2 * nvec : nvec;
+    constexpr int MQ = M / 4;
     float c[1][M], f0[1][M], f1[1][M];
 
     // All of the row's coalesced loads (16 B per lane, 1 KiB per instruction) are issued before the
@@ -28,8 +36,9 @@ __global__ void __launch_bounds__(64, 2) wave_hpass_kernel(WavePassArgs a)
     float4 tC[M / 4], t0[M / 4], t1[M / 4];
     {
         const float4* sC = reinterpret_cast<const float4*>(a.C + off);
-        const float4* s0 = reinterpret_cast<const float4*>(a.U0 + off);
-        const float4* s1 = (R > 1) ? reinterpret_cast<const float4*>(a.U1 + off) : nullptr;
+        // PAIR: t0 / t1 hold the first / second half of the interleaved row instead of U0 / U1
+        const float4* s0 = reinterpret_cast<const float4*>(a.U0 + offU);
+        const float4* s1 = PAIR ? s0 + 64 * MQ : nullptr;
         // fused inputs (the launcher guarantees 16 / 8 byte alignment and len % 4 == 0)
         const float4* sF = nullptr; const short4* sD = nullptr;
         if (FUSED) {
@@ -53,13 +62,12 @@ __global__ void __launch_bounds__(64, 2) wave_hpass_kernel(WavePassArgs a)
                     t1[k] = cf;
                     t0[k] = make_float4(cf.x * (float)dd.x, cf.y * (float)dd.y, cf.z * (float)dd.z, cf.w * (float)dd.w);
                 }
-            } else if (idx < nvec) {
-                // non-temporal: every byte of a row pass is used exactly once (measured -5 % on the pass;
-                // the vertical pass must NOT do this: its paired strips rely on L2 to share 128-byte lines)
-                { typedef float v4f __attribute__((ext_vector_type(4)));
-                  v4f a = __builtin_nontemporal_load(reinterpret_cast<const v4f*>(sC) + idx); tC[k] = make_float4(a.x, a.y, a.z, a.w);
-                  a = __builtin_nontemporal_load(reinterpret_cast<const v4f*>(s0) + idx); t0[k] = make_float4(a.x, a.y, a.z, a.w);
-                  if (R > 1) { a = __builtin_nontemporal_load(reinterpret_cast<const v4f*>(s1) + idx); t1[k] = make_float4(a.x, a.y, a.z, a.w); } }
+            } else {
+                // non-temporal: every byte of a row pass is used exactly once (measured -5 % on the pass)
+                typedef float v4f __attribute__((ext_vector_type(4)));
+                if (idx < nvec) { const v4f q = __builtin_nontemporal_load(reinterpret_cast<const v4f*>(sC) + idx); tC[k] = make_float4(q.x, q.y, q.z, q.w); }
+                if (idx < nvecU) { const v4f q = __builtin_nontemporal_load(reinterpret_cast<const v4f*>(s0) + idx); t0[k] = make_float4(q.x, q.y, q.z, q.w); }
+                if (PAIR && idx + 64 * MQ < nvecU) { const v4f q = __builtin_nontemporal_load(reinterpret_cast<const v4f*>(s1) + idx); t1[k] = make_float4(q.x, q.y, q.z, q.w); }
             }
         }
     }
@@ -77,13 +85,37 @@ __global__ void __launch_bounds__(64, 2) wave_hpass_kernel(WavePassArgs a)
         }                                                                                 \
         __syncthreads();                                                                  \
     }
-    ADF_TRANSPOSE_IN(tC, c[0], a.lambda)
-    ADF_TRANSPOSE_IN(t0, f0[0], 1.0f)
-    if (R > 1) ADF_TRANSPOSE_IN(t1, f1[0], 1.0f)
-    else {
-#pragma unroll
-        for (int i = 0; i < M; i++) f1[0][i] = 0.0f;
+    // PAIR, not fused: half HALF of the interleaved row (strips [2M*HALF, 2M*HALF + 2M)) holds both
+    // right-hand sides of the chunks of lanes [32*HALF, 32*HALF + 32); float4 #q of a chunk starts at
+    // column j = lane'*M + 4q of the half, i.e. at float4 8*(j/16) + (j%16)/4 (+4 for U1) of the stage.
+#define ADF_PAIR_IN(T, HALF)                                                              \
+    {                                                                                     \
+        _Pragma("unroll") for (int k = 0; k < MQ; k++) stage[64 * k + lane] = T[k];       \
+        __syncthreads();                                                                  \
+        if ((lane >> 5) == (HALF)) {                                                      \
+            _Pragma("unroll") for (int k = 0; k < MQ; k++) {                              \
+                const int j = (lane & 31) * M + 4 * k;                                    \
+                const int sidx = ((j >> 4) << 3) + ((j & 15) >> 2);                       \
+                const float4 v = stage[sidx], w = stage[sidx + 4];                        \
+                f0[0][4 * k + 0] = v.x; f0[0][4 * k + 1] = v.y; f0[0][4 * k + 2] = v.z; f0[0][4 * k + 3] = v.w; \
+                f1[0][4 * k + 0] = w.x; f1[0][4 * k + 1] = w.y; f1[0][4 * k + 2] = w.z; f1[0][4 * k + 3] = w.w; \
+            }                                                                             \
+        }                                                                                 \
+        __syncthreads();                                                                  \
     }
+    ADF_TRANSPOSE_IN(tC, c[0], a.lambda)
+    if (PAIR && !FUSED) {
+        ADF_PAIR_IN(t0, 0)
+        ADF_PAIR_IN(t1, 1)
+    } else {
+        ADF_TRANSPOSE_IN(t0, f0[0], 1.0f)
+        if (R > 1) ADF_TRANSPOSE_IN(t1, f1[0], 1.0f)
+        else {
+#pragma unroll
+            for (int i = 0; i < M; i++) f1[0][i] = 0.0f;
+        }
+    }
+#undef ADF_PAIR_IN
 #undef ADF_TRANSPOSE_IN
 
     float a_s[1] = {__shfl_up(c[0][M - 1], 1)};
@@ -101,22 +133,41 @@ __global__ void __launch_bounds__(64, 2) wave_hpass_kernel(WavePassArgs a)
     if (lane == 0) { xL0[0] = 0.0f; xL1[0] = 0.0f; }
     chunk_solve<M, R, 1>(c, f0, f1, a_s, xL0, xL1, xs0, xs1);
 
-    auto store_row = [&](float* dstp, const float (&src)[M]) {
+    typedef float v4f __attribute__((ext_vector_type(4)));
+    if (!PAIR) {
 #pragma unroll
-        for (int k = 0; k < M / 4; k++)
-            stage[lane * (M / 4) + k] = make_float4(src[4 * k], src[4 * k + 1], src[4 * k + 2], src[4 * k + 3]);
+        for (int k = 0; k < MQ; k++)
+            stage[lane * MQ + k] = make_float4(f0[0][4 * k], f0[0][4 * k + 1], f0[0][4 * k + 2], f0[0][4 * k + 3]);
         __syncthreads();
-        float4* d4 = reinterpret_cast<float4*>(dstp + off);
+        v4f* d4 = reinterpret_cast<v4f*>(a.U0 + off);
 #pragma unroll
-        for (int k = 0; k < M / 4; k++) {
+        for (int k = 0; k < MQ; k++) {
             const int idx = 64 * k + lane;
-            if (idx < nvec) { typedef float v4f __attribute__((ext_vector_type(4))); const float4 q = stage[idx]; v4f a = {q.x, q.y, q.z, q.w};
-                              __builtin_nontemporal_store(a, reinterpret_cast<v4f*>(d4) + idx); }
+            if (idx < nvec) { const float4 q = stage[idx]; const v4f o = {q.x, q.y, q.z, q.w}; __builtin_nontemporal_store(o, d4 + idx); }
         }
-        __syncthreads();
-    };
-    store_row(a.U0, f0[0]);
-    if (R > 1) store_row(a.U1, f1[0]);
+    } else {
+        // the mirror image of ADF_PAIR_IN: half a row of the pair plane at a time
+        v4f* d4 = reinterpret_cast<v4f*>(a.U0 + offU);
+#pragma unroll
+        for (int half = 0; half < 2; half++) {
+            if ((lane >> 5) == half) {
+#pragma unroll
+                for (int k = 0; k < MQ; k++) {
+                    const int j = (lane & 31) * M + 4 * k;
+                    const int sidx = ((j >> 4) << 3) + ((j & 15) >> 2);
+                    stage[sidx] = make_float4(f0[0][4 * k], f0[0][4 * k + 1], f0[0][4 * k + 2], f0[0][4 * k + 3]);
+                    stage[sidx + 4] = make_float4(f1[0][4 * k], f1[0][4 * k + 1], f1[0][4 * k + 2], f1[0][4 * k + 3]);
+                }
+            }
+            __syncthreads();
+#pragma unroll
+            for (int k = 0; k < MQ; k++) {
+                const int idx = 64 * (k + half * MQ) + lane;
+                if (idx < nvecU) { const float4 q = stage[64 * k + lane]; const v4f o = {q.x, q.y, q.z, q.w}; __builtin_nontemporal_store(o, d4 + idx); }
+            }
+            __syncthreads();
+        }
+    }
 }
 
 template <int M>

@@ -24,8 +24,9 @@ __global__ void __launch_bounds__(VT) wave_vpass_kernel(WavePassArgs a)
     __shared__ float xs[2][VC][64];   // separator solutions
     const int tid = threadIdx.x;
     const int xp = tid & 7, cidx = tid >> 3;
-    // A strip row is a 64-byte half of a 128-byte line of the float planes (and a 32-byte quarter of a
-    // line of the int16 output); the rest of the line belongs to the neighbouring strips.  Blocks b,
+    // A strip row is a 64-byte half of a 128-byte line of a single right-hand-side plane (R == 1) and a
+    // 32-byte quarter of a line of the int16 output; the rest of the line belongs to the neighbouring
+    // strips (the pair plane of R == 2 and the weights are laid out so that this does not happen).  Blocks b,
     // b+8, b+16, b+24 are dealt to the same XCD back to back (speed only, never correctness), so four
     // consecutive strips are mapped to them: later requests for a line hit (or merge in) that XCD's L2
     // instead of going to the fabric again, and partial-line writes combine there before eviction.
@@ -42,19 +43,28 @@ __global__ void __launch_bounds__(VT) wave_vpass_kernel(WavePassArgs a)
     const int r0 = cidx * M;
     const int h = a.len;                            // scanline length = ROI height
 
-    // Addressing: wave-uniform plane bases (SGPRs) + one 32-bit byte offset per thread that walks down
-    // the rows.  Keeping a 64-bit address per row alive from the loads to the stores would cost more
+    // Addressing: wave-uniform plane bases (SGPRs) + 32-bit byte offsets per thread that walk down the
+    // rows.  Keeping a 64-bit address per row alive from the loads to the stores would cost more
     // registers than the strip itself.
+    //   C (Cvert)  strip-major [strip][row][16]: the strip's weights are one contiguous stream
+    //   R == 2     pair plane [row][strip][U0 x16 | U1 x16]: a strip row is one full 128-byte line
+    //   R == 1     plain row-major plane: a strip row is a 64-byte half line
+    // (see fgs_wave_common.h; measured -17 % on the pass against three row-major planes)
     const char* bC = reinterpret_cast<const char*>(a.C + pb);
-    char* b0 = reinterpret_cast<char*>(a.U0 + pb);
-    char* b1 = (R > 1) ? reinterpret_cast<char*>(a.U1 + pb) : nullptr;
-    const unsigned pitch_b = (unsigned)a.pitch * 4u;
-    const unsigned voff0 = ((unsigned)r0 * (unsigned)a.pitch + (unsigned)col) * 4u;
+    char* b0 = reinterpret_cast<char*>(a.U0 + (R > 1 ? 2 * pb : pb));
+    char* b1 = (R > 1) ? b0 + 4 * VC : nullptr;
+    const unsigned pitch_b = (unsigned)a.pitch * (R > 1 ? 8u : 4u);
+    const unsigned voff0 = (R > 1) ? ((unsigned)r0 * (unsigned)a.pitch * 2u + (unsigned)strip * (2u * VC) + 2u * xp) * 4u
+                                   : ((unsigned)r0 * (unsigned)a.pitch + (unsigned)col) * 4u;
+    const unsigned pitch_c = 4u * VC;
+    const unsigned coff0 = (((unsigned)strip * (unsigned)h + (unsigned)r0) * VC + 2u * xp) * 4u;
 
     float c[2][M], f0[2][M], f1[2][M];
-    const unsigned safe = (unsigned)col * 4u;
+    // row 0 of the column: always inside the planes
+    const unsigned safe = (R > 1) ? ((unsigned)strip * (2u * VC) + 2u * xp) * 4u : (unsigned)col * 4u;
+    const unsigned csafe = ((unsigned)strip * (unsigned)h * VC + 2u * xp) * 4u;
     {
-        unsigned voff = voff0;
+        unsigned voff = voff0, coff = coff0;
 #pragma unroll
         for (int i = 0; i < M; i++) {
             // rows past the end of the column are identity rows (c = 0, f = 0); their loads are
@@ -62,19 +72,19 @@ __global__ void __launch_bounds__(VT) wave_vpass_kernel(WavePassArgs a)
             // entirely past the end starts beyond it) so that no load sits under a divergent branch
             const bool ok = r0 + i < h;
             const unsigned vo = ok ? voff : safe;
-            const float2 vc = *reinterpret_cast<const float2*>(bC + vo);
+            const float2 vc = *reinterpret_cast<const float2*>(bC + (ok ? coff : csafe));
             const float2 v0 = *reinterpret_cast<const float2*>(b0 + vo);
             float2 v1 = make_float2(0.f, 0.f);
             if (R > 1) v1 = *reinterpret_cast<const float2*>(b1 + vo);
             c[0][i] = ok ? vc.x * a.lambda : 0.0f; c[1][i] = ok ? vc.y * a.lambda : 0.0f;
             f0[0][i] = ok ? v0.x : 0.0f; f0[1][i] = ok ? v0.y : 0.0f;
             f1[0][i] = ok ? v1.x : 0.0f; f1[1][i] = ok ? v1.y : 0.0f;
-            voff += pitch_b;
+            voff += pitch_b; coff += pitch_c;
         }
     }
     float a_s[2] = {0.0f, 0.0f};
     if (cidx > 0 && r0 - 1 < h) {
-        const float2 v = *reinterpret_cast<const float2*>(bC + (voff0 - pitch_b));
+        const float2 v = *reinterpret_cast<const float2*>(bC + (coff0 - pitch_c));
         a_s[0] = v.x * a.lambda; a_s[1] = v.y * a.lambda;
     }
 

@@ -149,6 +149,7 @@ __global__ void __launch_bounds__(NT) weights_stream_kernel(WeightArgs a)
     const int nrows = min(WS_ROWS, g.rh - y0) + 1;             // one extra row feeds the last vertical difference
     float* chor = a.chor + pz * g.plane;
     float* cvert = a.cvert + pz * g.plane;
+    const bool strip = a.cvert_orient == ORIENT_STRIP;
 
     for (int q = tid; q < LUT_HEAD; q += NT) lut_head[q] = a.lut[q];
 
@@ -196,8 +197,13 @@ __global__ void __launch_bounds__(NT) weights_stream_kernel(WeightArgs a)
                 if (okx) {
                     if (n < nrows - 1)                         // Chor of this row, FGS.cpp:607-614
                         ADF_ST(&chor[(size_t)i * g.pw + j], (j == g.rw - 1) ? 0.0f : lookup(hidx));
-                    if (n >= 1)                                // Cvert of the previous row, FGS.cpp:635-660
-                        ADF_ST(&cvert[(size_t)(i - 1) * g.pw + j], (i - 1 == g.rh - 1) ? 0.0f : lookup(vidx));
+                    if (n >= 1) {                              // Cvert of the previous row, FGS.cpp:635-660
+                        // strip-major (ORIENT_STRIP): 16 lanes write one 64-byte piece of the strip's stream
+                        // per row and the following rows complete the line, so plain stores (L2 merges them)
+                        const float v = (i - 1 == g.rh - 1) ? 0.0f : lookup(vidx);
+                        if (strip) cvert[strip_index(i - 1, j, g.rh)] = v;
+                        else ADF_ST(&cvert[(size_t)(i - 1) * g.pw + j], v);
+                    }
                 }
             }
         }
@@ -208,7 +214,7 @@ __global__ void __launch_bounds__(NT) weights_stream_kernel(WeightArgs a)
 
 hipError_t launch_weights(const WeightArgs& a, int n_pairs, hipStream_t st)
 {
-    if (a.cvert_orient != ORIENT_N) return hipErrorInvalidValue;
+    if (a.cvert_orient != ORIENT_N && !(a.cvert_orient == ORIENT_STRIP && a.chor_orient == ORIENT_N)) return hipErrorInvalidValue;
     if (a.chor_orient == ORIENT_N) {   // wave solver: streaming kernel
         dim3 sgrid((a.g.rw + NT - 1) / NT, 1, n_pairs);
         {
