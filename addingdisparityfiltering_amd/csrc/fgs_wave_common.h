@@ -210,6 +210,135 @@ __device__ __forceinline__ void chunk_solve(float (&c)[NC][M], float (&f0)[NC][M
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Two-column versions for the vertical pass.  A thread owns the same rows of two adjacent columns;
+// written on 2-vectors the sweeps compile to the packed fp32 instructions (v_pk_fma_f32, v_pk_mul_f32,
+// v_pk_add_f32: two lanes of work per issue slot), and the register pair an 8-byte load fills is the
+// pair the arithmetic and the 8-byte store use -- no moves between "two scalars" and "a pair".  The
+// operations and their order are exactly those of the scalar templates above (v_rcp_f32 has no packed
+// form and is issued per element), so results are bit-identical to them.
+// ---------------------------------------------------------------------------------------------
+typedef float v2f __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ v2f vfma(v2f a, v2f b, v2f c) { return __builtin_elementwise_fma(a, b, c); }
+__device__ __forceinline__ v2f vsplat(float x) { return (v2f){x, x}; }
+template <bool REFINE>
+__device__ __forceinline__ v2f vrcp_sel(v2f x)
+{
+    const v2f r = {__builtin_amdgcn_rcpf(x.x), __builtin_amdgcn_rcpf(x.y)};
+    return REFINE ? vfma(vfma(-x, r, vsplat(1.0f)), r, r) : r;
+}
+
+template <int R>
+struct Boundary2 { v2f GS0, GS1, PS, QS, GE0, GE1, PE, QE; };
+
+template <int M, int R>
+__device__ __forceinline__ void chunk_boundary2(const v2f (&c)[M], const v2f (&f0)[M], const v2f (&f1)[M], v2f a_s, Boundary2<R>& o)
+{
+    constexpr bool NRB = ADF_WAVE_REFINE_BOUNDARY != 0;
+    const v2f one = vsplat(1.0f), zero = vsplat(0.0f);
+    // left -> right: x_i + D_i x_{i+1} = g_i - p_i xL;   right -> left: x_i + E_i x_{i-1} = h_i - q_i xR
+    v2f D, g0, g1, p, r, h0, h1, q;
+    {
+        const v2f rl = vrcp_sel<NRB>((one - a_s) - c[0]);
+        D = c[0] * rl; g0 = f0[0] * rl; g1 = (R > 1) ? f1[0] * rl : zero; p = a_s * rl;
+        const v2f ci = c[M - 2];
+        const v2f ar = (M - 2 == 0) ? a_s : c[(M - 3 > 0) ? M - 3 : 0];
+        r = vrcp_sel<NRB>((one - ar) - ci);
+        h0 = f0[M - 2] * r; h1 = (R > 1) ? f1[M - 2] * r : zero; q = ci * r;
+    }
+#pragma unroll
+    for (int t = 1; t <= M - 2; t++) {
+        const int i = t, j = M - 2 - t; // LU element, UL element
+        {
+            const v2f a = c[i - 1];
+            const v2f b = (one - a) - c[i];
+            const v2f rl = vrcp_sel<NRB>(vfma(-a, D, b));
+            D = c[i] * rl;
+            g0 = vfma(-a, g0, f0[i]) * rl;
+            if (R > 1) g1 = vfma(-a, g1, f1[i]) * rl;
+            p = (-a * p) * rl;
+            // pin every chain to its step: pure arithmetic is not ordered against the fence below by
+            // instruction selection, and a chain that drifts out of the loop drags one reciprocal per
+            // step along with it (the right-hand-side chains feed nothing until the end)
+            if (R > 1) asm volatile("" : "+v"(g0), "+v"(g1), "+v"(p));
+            else asm volatile("" : "+v"(g0), "+v"(p));
+        }
+        {
+            // opaque copies: without them the compiler shares b_j = 1 - a_j - c_j between the two
+            // sweeps and keeps it alive from one sweep's visit of j to the other's
+            v2f ci = c[j];
+            v2f a = (j == 0) ? a_s : c[(j > 0) ? j - 1 : 0];
+            asm volatile("" : "+v"(ci), "+v"(a));
+            const v2f b = (one - a) - ci;
+            r = vrcp_sel<NRB>(vfma(-ci * ci, r, b));
+            h0 = vfma(-ci, h0, f0[j]) * r;
+            if (R > 1) h1 = vfma(-ci, h1, f1[j]) * r;
+            q = (-ci * q) * r;
+            if (R > 1) asm volatile("" : "+v"(h0), "+v"(h1), "+v"(q));
+            else asm volatile("" : "+v"(h0), "+v"(q));
+        }
+        ADF_STEP_FENCE();
+    }
+    o.GE0 = g0; o.GE1 = g1; o.PE = p; o.QE = D;
+    o.GS0 = h0; o.GS1 = h1; o.PS = a_s * r; o.QS = q;
+}
+
+template <int M, int R>
+__device__ __forceinline__ void chunk_solve2(v2f (&c)[M], v2f (&f0)[M], v2f (&f1)[M], v2f a_s, v2f xL0, v2f xL1, v2f xR0, v2f xR1)
+{
+    constexpr bool NRS = ADF_WAVE_REFINE_SOLVE != 0;
+    const v2f one = vsplat(1.0f), zero = vsplat(0.0f);
+#pragma unroll
+    for (int i = 0; i < M; i++) asm volatile("" : "+v"(c[i]));
+    v2f corig = c[0], D, g0, g1;
+    {
+        const v2f r = vrcp_sel<NRS>((one - a_s) - corig);
+        D = corig * r;
+        g0 = vfma(-a_s, xL0, f0[0]) * r;
+        g1 = (R > 1) ? vfma(-a_s, xL1, f1[0]) * r : zero;
+        c[0] = D; f0[0] = g0; if (R > 1) f1[0] = g1;
+    }
+#pragma unroll
+    for (int i = 1; i <= M - 2; i++) {
+        const v2f a = corig;
+        corig = c[i];
+        const v2f b = (one - a) - corig;
+        const v2f r = vrcp_sel<NRS>(vfma(-a, D, b));
+        D = corig * r;
+        g0 = vfma(-a, g0, f0[i]) * r;
+        if (R > 1) g1 = vfma(-a, g1, f1[i]) * r;
+        c[i] = D; f0[i] = g0; if (R > 1) f1[i] = g1;
+        if (R > 1) asm volatile("" : "+v"(D), "+v"(g0), "+v"(g1));
+        else asm volatile("" : "+v"(D), "+v"(g0));
+        ADF_STEP_FENCE();
+    }
+    v2f x0 = xR0, x1 = xR1;
+    f0[M - 1] = x0; if (R > 1) f1[M - 1] = x1;
+#pragma unroll
+    for (int i = M - 2; i >= 0; i--) {
+        x0 = vfma(-c[i], x0, f0[i]);
+        f0[i] = x0;
+        if (R > 1) { x1 = vfma(-c[i], x1, f1[i]); f1[i] = x1; }
+        if (R > 1) asm volatile("" : "+v"(x0), "+v"(x1));
+        else asm volatile("" : "+v"(x0));
+        ADF_STEP_FENCE();
+    }
+}
+
+template <int M, int R>
+__device__ __forceinline__ void separator_row2(const v2f (&c)[M], const v2f (&f0)[M], const v2f (&f1)[M], const Boundary2<R>& o,
+                                               v2f nGS0, v2f nGS1, v2f nPS, v2f nQS, v2f& al, v2f& be, v2f& ga, v2f& p0, v2f& p1)
+{
+    const v2f ae = c[M - 2], ce = c[M - 1];
+    const v2f bb = (vsplat(1.0f) - ae) - ce;
+    al = -ae * o.PE;
+    be = vfma(-ce, nPS, vfma(-ae, o.QE, bb));
+    ga = -ce * nQS;
+    p0 = vfma(-ce, nGS0, vfma(-ae, o.GE0, f0[M - 1]));
+    p1 = (R > 1) ? vfma(-ce, nGS1, vfma(-ae, o.GE1, f1[M - 1])) : vsplat(0.0f);
+}
+
 // Separator equation of a chunk: alpha*x_prev + beta*x + gamma*x_next = phi.
 // nGS*/nPS/nQS are the NEXT chunk's left-end coefficients (zero for the last chunk).
 template <int M, int R>

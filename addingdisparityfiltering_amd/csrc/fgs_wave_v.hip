@@ -59,56 +59,55 @@ __global__ void __launch_bounds__(VT) wave_vpass_kernel(WavePassArgs a)
     const unsigned pitch_c = 4u * VC;
     const unsigned coff0 = (((unsigned)strip * (unsigned)h + (unsigned)r0) * VC + 2u * xp) * 4u;
 
-    float c[2][M], f0[2][M], f1[2][M];
+    // both columns of a row in one register pair, from the 8-byte load to the 8-byte store (see the
+    // two-column templates in fgs_wave_common.h)
+    v2f c[M], f0[M], f1[M];
     // row 0 of the column: always inside the planes
     const unsigned safe = (R > 1) ? ((unsigned)strip * (2u * VC) + 2u * xp) * 4u : (unsigned)col * 4u;
     const unsigned csafe = ((unsigned)strip * (unsigned)h * VC + 2u * xp) * 4u;
     {
+        // Rows past the end of the column are loaded from row 0 of the same column (always inside the
+        // planes, no load under a divergent branch) and NOT masked: Cvert is 0 in the last row
+        // (FGS.cpp:658-660), so whatever finite, diagonally dominant system those rows form is decoupled
+        // from the real one by exact zeros (0 * finite), and the stores below skip them.  Untouched
+        // loaded pairs stay where the load put them -- a select here would copy every pair.
         unsigned voff = voff0, coff = coff0;
+        const v2f lam = vsplat(a.lambda);
 #pragma unroll
         for (int i = 0; i < M; i++) {
-            // rows past the end of the column are identity rows (c = 0, f = 0); their loads are
-            // redirected to row 0 of the column (always inside the plane, whereas a chunk that lies
-            // entirely past the end starts beyond it) so that no load sits under a divergent branch
             const bool ok = r0 + i < h;
             const unsigned vo = ok ? voff : safe;
-            const float2 vc = *reinterpret_cast<const float2*>(bC + (ok ? coff : csafe));
-            const float2 v0 = *reinterpret_cast<const float2*>(b0 + vo);
-            float2 v1 = make_float2(0.f, 0.f);
-            if (R > 1) v1 = *reinterpret_cast<const float2*>(b1 + vo);
-            c[0][i] = ok ? vc.x * a.lambda : 0.0f; c[1][i] = ok ? vc.y * a.lambda : 0.0f;
-            f0[0][i] = ok ? v0.x : 0.0f; f0[1][i] = ok ? v0.y : 0.0f;
-            f1[0][i] = ok ? v1.x : 0.0f; f1[1][i] = ok ? v1.y : 0.0f;
+            c[i] = *reinterpret_cast<const v2f*>(bC + (ok ? coff : csafe));
+            f0[i] = *reinterpret_cast<const v2f*>(b0 + vo);
+            f1[i] = (R > 1) ? *reinterpret_cast<const v2f*>(b1 + vo) : vsplat(0.0f);
             voff += pitch_b; coff += pitch_c;
+            ADF_STEP_FENCE();   // one row's addresses at a time: hoisting all of them costs 2 registers per row
         }
+#pragma unroll
+        for (int i = 0; i < M; i++) c[i] *= lam;
     }
-    float a_s[2] = {0.0f, 0.0f};
-    if (cidx > 0 && r0 - 1 < h) {
-        const float2 v = *reinterpret_cast<const float2*>(bC + (coff0 - pitch_c));
-        a_s[0] = v.x * a.lambda; a_s[1] = v.y * a.lambda;
-    }
+    v2f a_s = vsplat(0.0f);
+    if (cidx > 0 && r0 - 1 < h) a_s = *reinterpret_cast<const v2f*>(bC + (coff0 - pitch_c)) * vsplat(a.lambda);
 
-    Boundary<R> bd[2];
-    chunk_boundary<M, R, 2>(c, f0, f1, a_s, bd);
-#pragma unroll
-    for (int e = 0; e < 2; e++) {
-        nb[0][cidx][2 * xp + e] = bd[e].GS0;
-        nb[1][cidx][2 * xp + e] = bd[e].GS1;
-        nb[2][cidx][2 * xp + e] = bd[e].PS;
-        nb[3][cidx][2 * xp + e] = bd[e].QS;
-    }
+    Boundary2<R> bd;
+    chunk_boundary2<M, R>(c, f0, f1, a_s, bd);
+    *reinterpret_cast<v2f*>(&nb[0][cidx][2 * xp]) = bd.GS0;
+    *reinterpret_cast<v2f*>(&nb[1][cidx][2 * xp]) = bd.GS1;
+    *reinterpret_cast<v2f*>(&nb[2][cidx][2 * xp]) = bd.PS;
+    *reinterpret_cast<v2f*>(&nb[3][cidx][2 * xp]) = bd.QS;
     __syncthreads();
-#pragma unroll
-    for (int e = 0; e < 2; e++) {
-        float nGS0 = 0.f, nGS1 = 0.f, nPS = 0.f, nQS = 0.f;
+    {
+        v2f nGS0 = vsplat(0.f), nGS1 = nGS0, nPS = nGS0, nQS = nGS0;
         if (cidx < 63) {
-            nGS0 = nb[0][cidx + 1][2 * xp + e]; nGS1 = nb[1][cidx + 1][2 * xp + e];
-            nPS = nb[2][cidx + 1][2 * xp + e]; nQS = nb[3][cidx + 1][2 * xp + e];
+            nGS0 = *reinterpret_cast<const v2f*>(&nb[0][cidx + 1][2 * xp]); nGS1 = *reinterpret_cast<const v2f*>(&nb[1][cidx + 1][2 * xp]);
+            nPS = *reinterpret_cast<const v2f*>(&nb[2][cidx + 1][2 * xp]); nQS = *reinterpret_cast<const v2f*>(&nb[3][cidx + 1][2 * xp]);
         }
-        float al, be, ga, p0, p1;
-        separator_row<M, R>(c[e], f0[e], f1[e], bd[e], nGS0, nGS1, nPS, nQS, al, be, ga, p0, p1);
-        red[0][2 * xp + e][cidx] = al; red[1][2 * xp + e][cidx] = be; red[2][2 * xp + e][cidx] = ga;
-        red[3][2 * xp + e][cidx] = p0; red[4][2 * xp + e][cidx] = p1;
+        v2f al, be, ga, p0, p1;
+        separator_row2<M, R>(c, f0, f1, bd, nGS0, nGS1, nPS, nQS, al, be, ga, p0, p1);
+        red[0][2 * xp][cidx] = al.x; red[1][2 * xp][cidx] = be.x; red[2][2 * xp][cidx] = ga.x;
+        red[3][2 * xp][cidx] = p0.x; red[4][2 * xp][cidx] = p1.x;
+        red[0][2 * xp + 1][cidx] = al.y; red[1][2 * xp + 1][cidx] = be.y; red[2][2 * xp + 1][cidx] = ga.y;
+        red[3][2 * xp + 1][cidx] = p0.y; red[4][2 * xp + 1][cidx] = p1.y;
     }
     __syncthreads();
     {   // 8 wavefronts x 2 columns each: one separator row per lane
@@ -123,14 +122,14 @@ __global__ void __launch_bounds__(VT) wave_vpass_kernel(WavePassArgs a)
     }
     __syncthreads();
     {
-        float xL0[2], xL1[2], xR0[2], xR1[2];
-#pragma unroll
-        for (int e = 0; e < 2; e++) {
-            const int cc = 2 * xp + e;
-            xR0[e] = xs[0][cc][cidx]; xR1[e] = xs[1][cc][cidx];
-            xL0[e] = cidx > 0 ? xs[0][cc][cidx - 1] : 0.0f; xL1[e] = cidx > 0 ? xs[1][cc][cidx - 1] : 0.0f;
+        const int cc = 2 * xp;
+        const v2f xR0 = {xs[0][cc][cidx], xs[0][cc + 1][cidx]}, xR1 = {xs[1][cc][cidx], xs[1][cc + 1][cidx]};
+        v2f xL0 = vsplat(0.0f), xL1 = xL0;
+        if (cidx > 0) {
+            xL0 = (v2f){xs[0][cc][cidx - 1], xs[0][cc + 1][cidx - 1]};
+            xL1 = (v2f){xs[1][cc][cidx - 1], xs[1][cc + 1][cidx - 1]};
         }
-        chunk_solve<M, R, 2>(c, f0, f1, a_s, xL0, xL1, xR0, xR1);
+        chunk_solve2<M, R>(c, f0, f1, a_s, xL0, xL1, xR0, xR1);
     }
 
     unsigned voff = voff0;
@@ -139,8 +138,8 @@ __global__ void __launch_bounds__(VT) wave_vpass_kernel(WavePassArgs a)
 #pragma unroll
         for (int i = 0; i < M; i++) {
             if (r0 + i < h) {
-                *reinterpret_cast<float2*>(b0 + voff) = make_float2(f0[0][i], f0[1][i]);
-                if (R > 1) *reinterpret_cast<float2*>(b1 + voff) = make_float2(f1[0][i], f1[1][i]);
+                *reinterpret_cast<v2f*>(b0 + voff) = f0[i];
+                if (R > 1) *reinterpret_cast<v2f*>(b1 + voff) = f1[i];
             }
             voff += pitch_b;
         }
@@ -158,10 +157,10 @@ __global__ void __launch_bounds__(VT) wave_vpass_kernel(WavePassArgs a)
 #pragma unroll
                     for (int e = 0; e < 2; e++) {
                         if (EPI == EPI_WLS_CONF) {
-                            const float rcp = 1.0f / (f1[e][i] + ADF_EPS);                 // DF.cpp:295
-                            v[e] = sat16(f0[e][i] * rcp);                                  // DF.cpp:296
+                            const float rcp = 1.0f / (f1[i][e] + ADF_EPS);                 // DF.cpp:295
+                            v[e] = sat16(f0[i][e] * rcp);                                  // DF.cpp:296
                         } else
-                            v[e] = sat16(f0[e][i]);
+                            v[e] = sat16(f0[i][e]);
                     }
                     char* dst = ob + ooff;
                     if ((reinterpret_cast<uintptr_t>(dst) & 3u) == 0)
@@ -173,14 +172,14 @@ __global__ void __launch_bounds__(VT) wave_vpass_kernel(WavePassArgs a)
                         if (col + e < a.nscan) {
                             char* dst = ob + ooff + (unsigned)(e * a.out_cn * esz);
                             if (EPI == EPI_WLS_CONF) {
-                                const float rcp = 1.0f / (f1[e][i] + ADF_EPS);             // DF.cpp:295
-                                *reinterpret_cast<int16_t*>(dst) = sat16(f0[e][i] * rcp);  // DF.cpp:296
+                                const float rcp = 1.0f / (f1[i][e] + ADF_EPS);             // DF.cpp:295
+                                *reinterpret_cast<int16_t*>(dst) = sat16(f0[i][e] * rcp);  // DF.cpp:296
                             } else if (EPI == EPI_I16)
-                                *reinterpret_cast<int16_t*>(dst) = sat16(f0[e][i]);
+                                *reinterpret_cast<int16_t*>(dst) = sat16(f0[i][e]);
                             else if (EPI == EPI_U8)
-                                *reinterpret_cast<uint8_t*>(dst) = sat8(f0[e][i]);
+                                *reinterpret_cast<uint8_t*>(dst) = sat8(f0[i][e]);
                             else
-                                *reinterpret_cast<float*>(dst) = f0[e][i];
+                                *reinterpret_cast<float*>(dst) = f0[i][e];
                         }
                     }
                 }
