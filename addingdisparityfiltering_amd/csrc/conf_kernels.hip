@@ -139,12 +139,28 @@ __device__ __forceinline__ void lds_barrier()
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
 
+// Exact window sums of an int16 map from 32-bit full-rate integer operations only.  d*d (<= 2^30) is
+// formed once per pixel (24-bit multiply: int16 operands) and staged next to d; a tap of the horizontal
+// sum is one 8-byte LDS read and three adds -- d, and the two 16-bit halves of d*d, which the sub-dword
+// operand selectors take apart for free.  (Sums of the halves stay below 2^31 for any window the column
+// kernels support; the square sum is reassembled in double, where it is exact.)  64-bit integer adds
+// and shifts would need fewer instructions but issue at a quarter of the rate.
+struct WinSum {
+    int s1, lo, hi;
+    __device__ __forceinline__ void clear() { s1 = 0; lo = 0; hi = 0; }
+    __device__ __forceinline__ void tap(const int2 v) { s1 += v.x; lo += v.y & 0xffff; hi += (int)((unsigned)v.y >> 16); }
+    __device__ __forceinline__ void add(const WinSum& o) { s1 += o.s1; lo += o.lo; hi += o.hi; }
+    __device__ __forceinline__ void sub(const WinSum& o) { s1 -= o.s1; lo -= o.lo; hi -= o.hi; }
+    __device__ __forceinline__ double sum2() const { return (double)hi * 65536.0 + (double)lo; }
+    __device__ static __forceinline__ int2 stage(int d) { return make_int2(d, __mul24(d, d)); }
+};
+
 template <int RT>
 __global__ void __launch_bounds__(NT) discontinuity_col_kernel(DiscArgs a)
 {
     constexpr int K = 2 * RT + 1;
     constexpr int OUTW = NT - 2 * RT;
-    __shared__ int rowbuf[2][NT];
+    __shared__ int2 rowbuf[2][NT];
     const int tid = threadIdx.x;
     const int rows_total = a.rh;
     const int view = a.only_view >= 0 ? a.only_view : (int)(blockIdx.z & 1);
@@ -167,8 +183,8 @@ __global__ void __launch_bounds__(NT) discontinuity_col_kernel(DiscArgs a)
     // rows are consumed in groups of U (a multiple of the window height K, so that ring slots stay
     // compile-time) and the next group's U loads are in flight while the current group is reduced
     constexpr int U = K * ((ADF_CONF_GROUP + K - 1) / K);
-    int r1[K], rlo[K], rhi[K];
-    int S1 = 0, Slo = 0, Shi = 0;
+    WinSum ring[K], S;
+    S.clear();
     int nxt[U];
 #pragma unroll
     for (int s = 0; s < U; s++) nxt[s] = (s < nrows) ? load(s) : 0;
@@ -182,24 +198,21 @@ __global__ void __launch_bounds__(NT) discontinuity_col_kernel(DiscArgs a)
             constexpr int dummy = 0; (void)dummy;
             const int slot = s % K;                               // compile-time after unrolling
             if (n < nrows) {                                     // block-uniform
-                rowbuf[n & 1][tid] = cur[s];
+                rowbuf[n & 1][tid] = WinSum::stage(cur[s]);
                 lds_barrier();
-                int h1 = 0, hlo = 0, hhi = 0;
+                WinSum hsum;
+                hsum.clear();
                 if (tid >= RT && tid < NT - RT) {
 #pragma unroll
-                    for (int d = -RT; d <= RT; d++) {
-                        const int v = rowbuf[n & 1][tid + d];
-                        const int q = v * v;                      // <= 2^30
-                        h1 += v; hlo += q & 0xffff; hhi += q >> 16;
-                    }
+                    for (int d = -RT; d <= RT; d++) hsum.tap(rowbuf[n & 1][tid + d]);
                 }
-                if (n >= K) { S1 -= r1[slot]; Slo -= rlo[slot]; Shi -= rhi[slot]; } // row n-K leaves the window
-                r1[slot] = h1; rlo[slot] = hlo; rhi[slot] = hhi;
-                S1 += h1; Slo += hlo; Shi += hhi;
+                if (n >= K) S.sub(ring[slot]);                    // row n-K leaves the window
+                ring[slot] = hsum;
+                S.add(hsum);
                 if (n >= 2 * RT && writer) {                     // window rows n-2RT..n are complete
                     const int oy = y_out0 + n - 2 * RT;
-                    const float mean = (float)((double)S1 * scale);
-                    const float sq = (float)(((double)Shi * 65536.0 + (double)Slo) * scale);
+                    const float mean = (float)((double)S.s1 * scale);
+                    const float sq = (float)(S.sum2() * scale);
                     const float variance = sq - mean * mean;      // DF.cpp:369
                     const float v = 1.0f - a.roll_off * variance; // DF.cpp:370
                     ADF_ST(&dst[(size_t)oy * a.W], v < 0.0f ? 0.0f : v);
@@ -222,7 +235,7 @@ __global__ void __launch_bounds__(NT) conf_left_kernel(ConfLeftArgs a)
     constexpr int OUTW = NT - 2 * RT;
     constexpr int U = K * ((ADF_LRC_GROUP + K - 1) / K);
     constexpr int CR = RT > 0 ? RT : 1;
-    __shared__ int rowbuf[2][NT];
+    __shared__ int2 rowbuf[2][NT];
     const Geom& g = a.g;
     const int tid = threadIdx.x;
     const int rows_total = g.rh;
@@ -250,8 +263,8 @@ __global__ void __launch_bounds__(NT) conf_left_kernel(ConfLeftArgs a)
     // window's CENTRE row, which this thread loaded itself RT rows before the window completes.  They
     // are issued for a whole group of rows as soon as the group's values have arrived and consumed as
     // the windows complete, so a group pays one memory latency instead of two per row.
-    int r1[K], rlo[K], rhi[K];
-    int S1 = 0, Slo = 0, Shi = 0;
+    WinSum ring[K], S;
+    S.clear();
     int nxt[U], cur[U];
     int gd[U]; float gc[U];                                       // gathered dR / cR of this group's centre rows
     int cd[CR], cdr[CR]; float ccr[CR];                           // carried over: last RT centre rows of the previous group
@@ -282,25 +295,22 @@ __global__ void __launch_bounds__(NT) conf_left_kernel(ConfLeftArgs a)
             const int n = n0 + s;
             const int slot = s % K;
             if (n < nrows) {                                     // block-uniform
-                rowbuf[n & 1][tid] = cur[s];
+                rowbuf[n & 1][tid] = WinSum::stage(cur[s]);
                 lds_barrier();
-                int h1 = 0, hlo = 0, hhi = 0;
+                WinSum hsum;
+                hsum.clear();
                 if (tid >= RT && tid < NT - RT) {
 #pragma unroll
-                    for (int d = -RT; d <= RT; d++) {
-                        const int v = rowbuf[n & 1][tid + d];
-                        const int q = v * v;
-                        h1 += v; hlo += q & 0xffff; hhi += q >> 16;
-                    }
+                    for (int d = -RT; d <= RT; d++) hsum.tap(rowbuf[n & 1][tid + d]);
                 }
-                if (n >= K) { S1 -= r1[slot]; Slo -= rlo[slot]; Shi -= rhi[slot]; }
-                r1[slot] = h1; rlo[slot] = hlo; rhi[slot] = hhi;
-                S1 += h1; Slo += hlo; Shi += hhi;
+                if (n >= K) S.sub(ring[slot]);
+                ring[slot] = hsum;
+                S.add(hsum);
                 if (n >= 2 * RT && writer) {                     // window centred on input row n-RT is complete
                     const int oy = y_out0 + n - 2 * RT;
                     const int i_abs = g.ry + oy;
-                    const float mean = (float)((double)S1 * scale);
-                    const float sq = (float)(((double)Shi * 65536.0 + (double)Slo) * scale);
+                    const float mean = (float)((double)S.s1 * scale);
+                    const float sq = (float)(S.sum2() * scale);
                     const float variance = sq - mean * mean;      // DF.cpp:369
                     float c = 1.0f - a.roll_off * variance;       // DF.cpp:370
                     c = c < 0.0f ? 0.0f : c;
