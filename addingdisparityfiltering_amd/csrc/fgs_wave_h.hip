@@ -1,6 +1,10 @@
 // fgs_wave_h.hip -- horizontal pass of the on-chip partitioned solver (see fgs_wave_common.h).
 #include "fgs_wave_common.h"
 
+#ifndef ADF_H_TWO_WAVE_MAX
+#define ADF_H_TWO_WAVE_MAX 60   // longest chunk whose two-right-hand-side kernel fits two waves per SIMD
+#endif
+
 namespace adf {
 
 namespace {
@@ -15,7 +19,7 @@ using namespace wave;
 // (the longest chunk with two right-hand sides does not fit two waves per SIMD without spilling: the
 // pair staging below keeps both right-hand sides and two of the three load batches alive at once)
 template <int M, int R, bool FUSED>
-__global__ void __launch_bounds__(64, (M >= 64 && R > 1) ? 1 : 2) wave_hpass_kernel(WavePassArgs a)
+__global__ void __launch_bounds__(64, (M > ADF_H_TWO_WAVE_MAX && R > 1) ? 1 : 2) wave_hpass_kernel(WavePassArgs a)
 {
     static_assert(M % 4 == 0 && M >= 4, "chunk length must be a multiple of 4");
     __shared__ float4 stage[M * 16];
@@ -134,6 +138,11 @@ __global__ void __launch_bounds__(64, (M >= 64 && R > 1) ? 1 : 2) wave_hpass_ker
     chunk_solve<M, R, 1>(c, f0, f1, a_s, xL0, xL1, xs0, xs1);
 
     typedef float v4f __attribute__((ext_vector_type(4)));
+    // The pass works in place: the store addresses ARE the load addresses, and the compiler would keep
+    // those (a 64-bit pointer per load) alive across the whole solve to reuse them.  An opaque copy of
+    // the lane index makes it recompute them here instead.
+    int lane_s = lane;
+    asm volatile("" : "+v"(lane_s));
     if (!PAIR) {
 #pragma unroll
         for (int k = 0; k < MQ; k++)
@@ -142,7 +151,7 @@ __global__ void __launch_bounds__(64, (M >= 64 && R > 1) ? 1 : 2) wave_hpass_ker
         v4f* d4 = reinterpret_cast<v4f*>(a.U0 + off);
 #pragma unroll
         for (int k = 0; k < MQ; k++) {
-            const int idx = 64 * k + lane;
+            const int idx = 64 * k + lane_s;
             if (idx < nvec) { const float4 q = stage[idx]; const v4f o = {q.x, q.y, q.z, q.w}; __builtin_nontemporal_store(o, d4 + idx); }
         }
     } else {
@@ -162,8 +171,8 @@ __global__ void __launch_bounds__(64, (M >= 64 && R > 1) ? 1 : 2) wave_hpass_ker
             __syncthreads();
 #pragma unroll
             for (int k = 0; k < MQ; k++) {
-                const int idx = 64 * (k + half * MQ) + lane;
-                if (idx < nvecU) { const float4 q = stage[64 * k + lane]; const v4f o = {q.x, q.y, q.z, q.w}; __builtin_nontemporal_store(o, d4 + idx); }
+                const int idx = 64 * (k + half * MQ) + lane_s;
+                if (idx < nvecU) { const float4 q = stage[64 * k + lane_s]; const v4f o = {q.x, q.y, q.z, q.w}; __builtin_nontemporal_store(o, d4 + idx); }
             }
             __syncthreads();
         }
@@ -210,6 +219,7 @@ hipError_t launch_wave_hpass(const WavePassArgs& a, int n_rhs, int n_pairs, hipS
     if (m <= 28) return launch_h<28>(a, n_rhs, n_pairs, st);
     if (m <= 40) return launch_h<40>(a, n_rhs, n_pairs, st);
     if (m <= 56) return launch_h<56>(a, n_rhs, n_pairs, st);
+    if (m <= 60) return launch_h<60>(a, n_rhs, n_pairs, st);   // 3840 columns: a full 4K row
     return launch_h<64>(a, n_rhs, n_pairs, st);
 }
 
