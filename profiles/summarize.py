@@ -1,0 +1,72 @@
+"""Turns what profiles/collect.sh left under gpurun_out/ into the committed summaries:
+
+  profiles/r01_<solver>_bench_n1.json          the bench line
+  profiles/r01_<solver>_bench_kernel_stats.csv rocprofv3 --kernel-trace --stats (kernel_stats), our kernels first
+  profiles/r01_<solver>_pmc_8pairs.csv         HBM bytes per launch from the FETCH_SIZE / WRITE_SIZE passes
+  profiles/pmc_traffic.json                    bytes per stereo pair per kernel (bench.py's roofline.traffic)
+
+FETCH_SIZE / WRITE_SIZE are in KB; on gfx950 FETCH_SIZE reports half of a coalesced streaming read
+(MI355X_MICROARCH.md, HBM section), so reads are doubled.
+"""
+import collections
+import csv
+import glob
+import json
+import os
+import re
+import shutil
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PAIRS = 8
+
+
+def short(name):
+    m = re.search(r"adf::\(anonymous namespace\)::([\w]+(?:<[^>]*>)?)", name)
+    return m.group(1) if m else None
+
+
+def counters(d, counter):
+    f = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
+    agg = collections.defaultdict(list)
+    for r in csv.DictReader(open(sorted(f, key=os.path.getmtime)[-1])):
+        k = short(r["Kernel_Name"])
+        if k and r["Counter_Name"] == counter:
+            agg[k].append(float(r["Counter_Value"]))
+    return agg
+
+
+def main(solver):
+    tag = os.path.join(ROOT, "gpurun_out", "r01_%s" % solver)
+    out = os.path.join(ROOT, "profiles", "r01_%s" % solver)
+    shutil.copy(tag + "_bench_n1.json", out + "_bench_n1.json")
+    st = glob.glob(os.path.join(tag + "_stats", "**", "*kernel_stats.csv"), recursive=True)
+    rows = list(csv.reader(open(sorted(st, key=os.path.getmtime)[-1])))
+    ours = [r for r in rows[1:] if "adf::" in r[0]]
+    rest = [r for r in rows[1:] if "adf::" not in r[0]]
+    with open(out + "_bench_kernel_stats.csv", "w", newline="") as f:
+        w = csv.writer(f, quoting=csv.QUOTE_ALL)
+        w.writerow(rows[0]); w.writerows(ours); w.writerows(rest)
+    fe, wr = counters(tag + "_pmc_fetch", "FETCH_SIZE"), counters(tag + "_pmc_write", "WRITE_SIZE")
+    tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    traffic = json.load(open(tpath)) if os.path.exists(tpath) else {}
+    per = {}
+    with open(out + "_pmc_8pairs.csv", "w") as f:
+        f.write("# rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes), bench.py --steps 1 --warmup 0 --pairs 8 (config 3, %s solver)\n" % solver)
+        f.write("# FETCH_SIZE is in KB and on gfx950 reports 1/2 of a coalesced streaming read (MI355X_MICROARCH.md, HBM): corrected_read = 2*FETCH_SIZE*1024\n")
+        f.write("kernel,dispatches,FETCH_SIZE_KB_avg,WRITE_SIZE_KB_avg,corrected_read_MB,write_MB,total_MB_per_launch,total_bytes_per_ROI_pixel\n")
+        for k in fe:
+            fk, wk = sum(fe[k]) / len(fe[k]), sum(wr[k]) / max(1, len(wr[k]))
+            rd, wt = 2 * fk * 1024, wk * 1024
+            px = 3584 * 2160 * PAIRS
+            f.write("%s,%d,%.1f,%.1f,%.1f,%.1f,%.1f,%.2f\n" % (k, len(fe[k]), fk, wk, rd / 1e6, wt / 1e6, (rd + wt) / 1e6, (rd + wt) / px))
+            per[k] = {"bytes_per_pair": (rd + wt) / PAIRS}
+    traffic["%s_cfg3" % solver] = per
+    traffic["_comment"] = ("HBM bytes per stereo pair and launch from rocprofv3 PMC passes (FETCH_SIZE doubled per the gfx950 "
+                           "correction + WRITE_SIZE); sources: profiles/r01_wave_pmc_8pairs.csv, profiles/r01_exact_pmc_8pairs.csv")
+    json.dump(traffic, open(tpath, "w"), indent=1)
+    print(open(out + "_pmc_8pairs.csv").read())
+
+
+if __name__ == "__main__":
+    main(sys.argv[1] if len(sys.argv) > 1 else "wave")
