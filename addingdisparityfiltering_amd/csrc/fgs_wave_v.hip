@@ -4,6 +4,29 @@
 // chunk length a 2160-row column needs and turns into scratch spills.
 #include "fgs_wave_common.h"
 
+#ifdef ADF_V_PHASE_TIMING
+// Measurement builds only (build.build_variant("vphase", ["ADF_V_PHASE_TIMING"]), tools/vphase.py): per-workgroup
+// phase time stamps of the plain column pass on the 100 MHz clock, plus the CU the workgroup ran on.
+__device__ unsigned long long adf_vphase[1 << 20];  // [wg][0..6 stamps, 7 = XCC_ID << 32 | HW_ID]
+__device__ unsigned long long adf_vwave[1 << 21];   // [wg][wave][start, end]
+extern "C" int adf_debug_read_vphase(unsigned long long* dst, int n)
+{
+    return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(adf_vphase), sizeof(unsigned long long) * (size_t)n);
+}
+extern "C" int adf_debug_read_vwave(unsigned long long* dst, int n)
+{
+    return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(adf_vwave), sizeof(unsigned long long) * (size_t)n);
+}
+#define ADF_WG_ID ((size_t)(((size_t)blockIdx.y * gridDim.x + blockIdx.x) % (1u << 17)))
+#define ADF_STAMP(k) do { if (EPI == EPI_PLANES && threadIdx.x == 0) adf_vphase[ADF_WG_ID * 8 + (k)] = wall_clock64(); } while (0)
+#define ADF_WSTAMP(k) do { if (EPI == EPI_PLANES && (threadIdx.x & 63) == 0) adf_vwave[(ADF_WG_ID * 8 + (threadIdx.x >> 6)) * 2 + (k)] = wall_clock64(); } while (0)
+#define ADF_DRAIN() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
+#else
+#define ADF_STAMP(k) do { } while (0)
+#define ADF_WSTAMP(k) do { } while (0)
+#define ADF_DRAIN() do { } while (0)
+#endif
+
 namespace adf {
 
 namespace {
@@ -24,6 +47,11 @@ __global__ void __launch_bounds__(VT) wave_vpass_kernel(WavePassArgs a)
     __shared__ float xs[2][VC][64];   // separator solutions
     const int tid = threadIdx.x;
     const int xp = tid & 7, cidx = tid >> 3;
+    ADF_STAMP(0); ADF_WSTAMP(0);
+#ifdef ADF_V_PHASE_TIMING
+    if (EPI == EPI_PLANES && threadIdx.x == 0)   // hwreg(HW_REG_XCC_ID) and hwreg(HW_REG_HW_ID), 32 bits each
+        adf_vphase[ADF_WG_ID * 8 + 7] = ((unsigned long long)__builtin_amdgcn_s_getreg(63508) << 32) | (unsigned)__builtin_amdgcn_s_getreg(63492);
+#endif
     // A strip row is a 64-byte half of a 128-byte line of a single right-hand-side plane (R == 1) and a
     // 32-byte quarter of a line of the int16 output; the rest of the line belongs to the neighbouring
     // strips (the pair plane of R == 2 and the weights are laid out so that this does not happen).  Blocks b,
@@ -89,8 +117,10 @@ __global__ void __launch_bounds__(VT) wave_vpass_kernel(WavePassArgs a)
     v2f a_s = vsplat(0.0f);
     if (cidx > 0 && r0 - 1 < h) a_s = *reinterpret_cast<const v2f*>(bC + (coff0 - pitch_c)) * vsplat(a.lambda);
 
+    ADF_DRAIN(); ADF_STAMP(1);
     Boundary2<R> bd;
     chunk_boundary2<M, R>(c, f0, f1, a_s, bd);
+    ADF_STAMP(2);
     *reinterpret_cast<v2f*>(&nb[0][cidx][2 * xp]) = bd.GS0;
     *reinterpret_cast<v2f*>(&nb[1][cidx][2 * xp]) = bd.GS1;
     *reinterpret_cast<v2f*>(&nb[2][cidx][2 * xp]) = bd.PS;
@@ -129,7 +159,9 @@ __global__ void __launch_bounds__(VT) wave_vpass_kernel(WavePassArgs a)
             xL0 = (v2f){xs[0][cc][cidx - 1], xs[0][cc + 1][cidx - 1]};
             xL1 = (v2f){xs[1][cc][cidx - 1], xs[1][cc + 1][cidx - 1]};
         }
+        ADF_STAMP(3);
         chunk_solve2<M, R>(c, f0, f1, a_s, xL0, xL1, xR0, xR1);
+        ADF_STAMP(4);
     }
 
     unsigned voff = voff0;
@@ -187,6 +219,7 @@ __global__ void __launch_bounds__(VT) wave_vpass_kernel(WavePassArgs a)
             ooff += (unsigned)a.out_stride;
         }
     }
+    ADF_STAMP(5); ADF_DRAIN(); ADF_STAMP(6); ADF_WSTAMP(1);
 }
 
 template <int M>
