@@ -282,6 +282,19 @@ struct adf_wls {
     // (geometry, solver) the workspace planes were last laid out for; a change re-zeroes them so that
     // pitch padding is zero again (the wave solver treats it as identity rows without masking)
     long long ws_sig[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    // side stream: the weight kernel (guide only) runs beside the confidence kernels (disparity maps only)
+    // of the same call, forked from and joined back into the caller's stream with events
+    hipStream_t side = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    bool overlap = true;
+    int ensure_side()
+    {
+        if (side) return ADF_OK;
+        HIP_TRY(hipStreamCreateWithFlags(&side, hipStreamNonBlocking));
+        HIP_TRY(hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming));
+        HIP_TRY(hipEventCreateWithFlags(&ev_join, hipEventDisableTiming));
+        return ADF_OK;
+    }
 };
 
 extern "C" int adf_wls_create(adf_wls_t** out, int use_confidence, int l, int r, int t, int b, int min_disp)
@@ -302,6 +315,7 @@ extern "C" int adf_wls_create(adf_wls_t** out, int use_confidence, int l, int r,
         double gb = atof(e);
         if (gb > 0) h->ws_limit = (size_t)(gb * (double)((size_t)1 << 30));
     }
+    if (const char* e = getenv("ADF_NO_OVERLAP")) h->overlap = atoi(e) == 0;   // measurement knob
     *out = h;
     return ADF_OK;
 }
@@ -312,6 +326,9 @@ extern "C" void adf_wls_destroy(adf_wls_t* h)
     DeviceScope ds(h->device);
     h->lut.dev.release(); h->ws.release(); h->conf.release(); h->stage.release(); h->scaled.release();
     h->prof.destroy();
+    if (h->ev_fork) hipEventDestroy(h->ev_fork);
+    if (h->ev_join) hipEventDestroy(h->ev_join);
+    if (h->side) hipStreamDestroy(h->side);
     delete h;
 }
 
@@ -458,10 +475,22 @@ static int wls_filter_impl(adf_wls_t* h, int n_pairs,
             HIP_TRY(launch_outside(oa, n, st));
         }
         WeightArgs wa{gv, sG, psG, gch, (const float*)h->lut.dev.p, p.CH, p.CV, orient_h, orient_cv, g};
-        {
-            ProfScope ps(prof, K_WEIGHTS, (gch + 8.0) * P, (gch + 8.0) * P, st);
-            HIP_TRY(launch_weights(wa, n, st));                            // FGS.cpp:163-172
+        // confidence mode: the weights depend on the guide only and the confidence kernels on the disparity
+        // maps only -- one is bound by memory latency, the others lean on the vector ALUs -- so the weight
+        // kernel is forked onto the side stream and joined before the first solve pass
+        const bool fork_weights = conf && h->overlap;
+        hipStream_t wst = st;
+        if (fork_weights) {
+            if ((rc = h->ensure_side())) return rc;
+            HIP_TRY(hipEventRecord(h->ev_fork, st));
+            HIP_TRY(hipStreamWaitEvent(h->side, h->ev_fork, 0));
+            wst = h->side;
         }
+        {
+            ProfScope ps(prof, K_WEIGHTS, (gch + 8.0) * P, (gch + 8.0) * P, wst);
+            HIP_TRY(launch_weights(wa, n, wst));                           // FGS.cpp:163-172
+        }
+        if (fork_weights) HIP_TRY(hipEventRecord(h->ev_join, h->side));
 
         if (conf) {
             const int16_t* dRp = (const int16_t*)((const char*)dispR + (ptrdiff_t)first * psR);
@@ -526,6 +555,7 @@ static int wls_filter_impl(adf_wls_t* h, int n_pairs,
                     HIP_TRY(launch_lrc_prologue(la, n, st));               // DF.cpp:208-209,288-290
                 }
             }
+            if (fork_weights) HIP_TRY(hipStreamWaitEvent(st, h->ev_join, 0));
             FinalOut fo{EPI_WLS_CONF, o, sO, psO, roi.x, roi.y, 1, 0};
             rc = wave ? run_passes_wave(g, p, 2, (float)h->lambda, (float)h->atten, h->num_iter, fo, n, st, prof,
                                         fuse.conf_in ? &fuse : nullptr)

@@ -59,10 +59,14 @@ __global__ void __launch_bounds__(64, (M > ADF_H_TWO_WAVE_MAX && R > 1) ? 1 : 2)
             const int idx = 64 * k + lane;
             tC[k] = make_float4(0.f, 0.f, 0.f, 0.f); t0[k] = tC[k]; t1[k] = tC[k];
             if (FUSED) {
-                if (idx < nvec) tC[k] = sC[idx];
+                typedef float v4f __attribute__((ext_vector_type(4)));
+                typedef short v4s __attribute__((ext_vector_type(4)));
+                if (idx < nvec) { const v4f q = __builtin_nontemporal_load(reinterpret_cast<const v4f*>(sC) + idx); tC[k] = make_float4(q.x, q.y, q.z, q.w); }
                 if (idx < nfused) {
-                    const float4 cf = sF[idx];
-                    const short4 dd = sD[idx];
+                    const v4f cq = __builtin_nontemporal_load(reinterpret_cast<const v4f*>(sF) + idx);
+                    const v4s dq = __builtin_nontemporal_load(reinterpret_cast<const v4s*>(sD) + idx);
+                    const float4 cf = make_float4(cq.x, cq.y, cq.z, cq.w);
+                    const short4 dd = make_short4(dq.x, dq.y, dq.z, dq.w);
                     t1[k] = cf;
                     t0[k] = make_float4(cf.x * (float)dd.x, cf.y * (float)dd.y, cf.z * (float)dd.z, cf.w * (float)dd.w);
                 }
