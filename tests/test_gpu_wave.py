@@ -126,6 +126,32 @@ def test_batch_equals_singles_and_full_width(adf, oracle):
         assert d.max() <= MAX_DIF and d.mean() <= MAX_MEAN_DIF
 
 
+# every chunk-length bucket of the row pass (fgs_wave_h.hip: 4..64 elements per lane), at a width that fills
+# it and at one just past the previous bucket, with an ROI the fused first pass accepts (x, width multiples
+# of 4) and one it must refuse (odd x / width: the pair plane is then written by the confidence kernel)
+@pytest.mark.parametrize("width", [256, 260, 512, 1024, 1100, 1280, 1792, 2500, 2560, 3584, 3700, 3840, 3844, 4096])
+@pytest.mark.parametrize("fusable", [True, False])
+def test_every_row_bucket(adf, oracle, width, fusable):
+    h = 40
+    view, dl, dr, _ = synthetic.make_artificial_example(width + 8, h, 3, seed=width, rect_disparity=64)
+    roi = (4, 0, width, h) if fusable else (3, 1, width - 1, h - 2)
+    diff, got, _ = _run(adf, oracle, dl, view, dr, roi, **{"sigma_color": 1.5})
+    assert diff.max() <= MAX_DIF and diff.mean() <= MAX_MEAN_DIF, (diff.max(), diff.mean())
+
+
+# every chunk-length bucket of the column pass (fgs_wave_v.hip: 2..34 rows per thread), columns that end
+# inside a chunk, exactly on a chunk boundary, and that leave whole chunks empty
+@pytest.mark.parametrize("height", [3, 128, 129, 200, 256, 500, 512, 700, 768, 1100, 1152, 1600, 1664, 2000, 2160, 2176])
+def test_every_column_bucket(adf, oracle, height):
+    w = 96
+    view, dl, dr, roi = synthetic.make_artificial_example(w, height, 3, seed=height, rect_disparity=16)
+    diff, _, _ = _run(adf, oracle, dl, view, dr, roi, **{"sigma_color": 1.5})
+    assert diff.max() <= MAX_DIF and diff.mean() <= MAX_MEAN_DIF, (diff.max(), diff.mean())
+    # the single right-hand-side layout (plain plane, 64-byte strip rows) through the same buckets
+    diff, _, _ = _run(adf, oracle, dl, view, dr, roi, use_conf=False, **{"sigma_color": 1.5})
+    assert diff.max() <= MAX_DIF and diff.mean() <= MAX_MEAN_DIF, (diff.max(), diff.mean())
+
+
 def test_falls_back_to_exact_beyond_register_capacity(adf, oracle):
     """Columns longer than 2176 rows do not fit the register-resident strip: exact solver takes over."""
     view, dl, dr, roi = synthetic.make_artificial_example(96, 2300, 1, seed=4, rect_disparity=10)
