@@ -37,8 +37,10 @@ def parse_args():
     ap.add_argument("--config", type=int, default=3, help="BASELINE.json config id (geometry)")
     ap.add_argument("--pairs", type=int, default=64, help="stereo pairs per GPU and step")
     ap.add_argument("--solver", choices=["exact", "wave"], default=os.environ.get("ADF_BENCH_SOLVER", "wave"))
-    ap.add_argument("--distribution", choices=["scatter", "local"], default="scatter",
-                    help="N>1: rank 0 builds the batch and scatters it over RCCL, or each rank builds its shard")
+    ap.add_argument("--distribution", choices=["scatter", "local"], default="local",
+                    help="N>1: each rank builds its own contiguous shard of the batch (default: the path shards "
+                         "with no data-path collective), or rank 0 builds the whole batch and scatters it / gathers "
+                         "the results over RCCL point-to-point groups (outside the timed region either way)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU baseline budget (0 = skip)")
     ap.add_argument("--no-check", action="store_true", help="skip the oracle check of pair 0")
     return ap.parse_args()
