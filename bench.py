@@ -204,7 +204,7 @@ def main():
     def bucket(v, bs):
         return next(b for b in bs if v <= b)
     if args.solver == "wave":
-        mh = bucket((roi[2] + 63) // 64, (4, 8, 16, 20, 28, 40, 56, 64))
+        mh = bucket((roi[2] + 63) // 64, (4, 8, 16, 20, 28, 40, 56, 60, 64))
         mv = bucket((roi[3] + 63) // 64, (2, 4, 8, 12, 18, 26, 34))
         names = {"pass_h": "wave_hpass_kernel<%d, 2, false>" % mh, "pass_v": "wave_vpass_kernel<%d, 2, 0>" % mv}
     else:
