@@ -19,10 +19,15 @@
 // along the other image axis, again finds its scanline index fastest.  The last pass of a filter
 // call fuses the epilogue (DF.cpp:295-296 / FGS.cpp:216) and writes the image row-major.
 //
-// HBM traffic per element and pass with R right-hand sides: forward read 4+4R, write 4+4R
-// (D and the eliminated right-hand sides do not fit on chip for a lane-per-scanline sweep),
-// backward read 4+4R, write 4R  =>  12+16R bytes (44 at R=2) against the algorithmic 4+8R.
-// This is the price of bit-exactness; ADF_SOLVER_WAVE removes it.
+// HBM traffic per element and pass with R right-hand sides.  D and the eliminated right-hand sides do
+// not fit on chip for a lane-per-scanline sweep, and spilling them costs 4+4R bytes written and read
+// again (12+16R in total, 44 at R=2).  Instead the forward sweep keeps only a checkpoint of its running
+// state every SEG steps, and the backward sweep walks the scanline segment by segment from the end:
+// it reloads the segment's inputs, repeats the forward recurrence from the checkpoint -- the same
+// operations on the same operands, hence the same bits -- with D and the right-hand sides of those SEG
+// steps in registers, and back-substitutes.  Forward read 4+4R, backward read 4+4R, write 4R, plus
+// (4+4R)/SEG of checkpoints: 8+12R+ bytes (32.4 at R=2) against the algorithmic 4+8R.  The rest is
+// the price of bit-exactness; ADF_SOLVER_WAVE removes it.
 #include "adf_internal.h"
 
 #pragma clang fp contract(off)
@@ -31,8 +36,8 @@ namespace adf {
 
 namespace {
 
-constexpr int PF = 8;        // steps per software-pipelined chunk (loads run one chunk ahead)
-constexpr int TT = 32;       // steps per transposed output block (128-byte segments)
+constexpr int PF = 8;        // steps per software-pipelined chunk of the forward sweep (loads run one chunk ahead)
+constexpr int SEG = 32;      // steps per checkpointed segment = steps per transposed output block (128-byte segments)
 constexpr int TPITCH = 36;   // LDS tile row pitch in floats: 16-byte aligned, conflict-free b128
 
 template <int R, int EPI>
@@ -49,20 +54,19 @@ __global__ void __launch_bounds__(64) exact_pass_kernel(PassArgs a)
     const float* pC = a.C + pb + s;
     const float* pU0 = a.U0 + pb + s;
     const float* pU1 = (R > 1) ? a.U1 + pb + s : nullptr;
+    // checkpoint k (row k of these planes, k >= 1): D, F0, F1 after step k*SEG - 1
     float* pD = a.D + pb + s;
     float* pF0 = a.F0 + pb + s;
     float* pF1 = (R > 1) ? a.F1 + pb + s : nullptr;
 
-    // ------------------------------ forward elimination ------------------------------
+    // ------------------------------ forward elimination: checkpoints only ------------------------------
     {
         float cp = lam * pC[0];
         const float om = 1.0f - cp;
         float d = cp / om;
         float f0 = pU0[0] / om;
         float f1 = 0.0f;
-        pD[0] = d;
-        pF0[0] = f0;
-        if (R > 1) { f1 = pU1[0] / om; pF1[0] = f1; }
+        if (R > 1) f1 = pU1[0] / om;
 
         float nc[PF], n0[PF], n1[PF];
 #pragma unroll
@@ -89,101 +93,115 @@ __global__ void __launch_bounds__(64) exact_pass_kernel(PassArgs a)
                     const float den = (1.0f - cp - cc) - d * cp;
                     d = cc / den;
                     f0 = (u0_[k] - f0 * cp) / den;
-                    const size_t o = (size_t)t * pitch;
-                    pD[o] = d;
-                    pF0[o] = f0;
-                    if (R > 1) { f1 = (u1_[k] - f1 * cp) / den; pF1[o] = f1; }
+                    if (R > 1) f1 = (u1_[k] - f1 * cp) / den;
                     cp = cc;
+                    if (((t + 1) & (SEG - 1)) == 0 && t + 1 < len) {   // state the next segment starts from
+                        const size_t o = (size_t)((t + 1) / SEG) * pitch;
+                        pD[o] = d;
+                        pF0[o] = f0;
+                        if (R > 1) pF1[o] = f1;
+                    }
                 }
             }
         }
     }
 
-    // ------------------------------ back substitution ------------------------------
+    // ------------------------- back substitution, one recomputed segment at a time -------------------------
     __shared__ __align__(16) float tile[(EPI == EPI_PLANES) ? R * 64 * TPITCH : 4];
     float x0 = 0.0f, x1 = 0.0f;
-    const int tb = ((len - 1) / PF) * PF;
-    float nd[PF], n0[PF], n1[PF];
+    const int nseg = (len + SEG - 1) / SEG;
+    for (int k = nseg - 1; k >= 0; k--) {
+        const int tb = k * SEG;
+        // D / F overwrite the inputs in place as the recurrence passes them
+        float c_[SEG], u0_[SEG], u1_[SEG];
 #pragma unroll
-    for (int k = 0; k < PF; k++) {
-        const size_t o = (size_t)min(tb + k, len - 1) * pitch;
-        nd[k] = pD[o]; n0[k] = pF0[o];
-        if (R > 1) n1[k] = pF1[o];
-    }
-    for (int t0 = tb; t0 >= 0; t0 -= PF) {
-        float d_[PF], f0_[PF], f1_[PF];
-#pragma unroll
-        for (int k = 0; k < PF; k++) { d_[k] = nd[k]; f0_[k] = n0[k]; if (R > 1) f1_[k] = n1[k]; }
-        if (t0 >= PF) {
-#pragma unroll
-            for (int k = 0; k < PF; k++) {
-                const size_t o = (size_t)(t0 - PF + k) * pitch;
-                nd[k] = pD[o]; n0[k] = pF0[o];
-                if (R > 1) n1[k] = pF1[o];
-            }
+        for (int j = 0; j < SEG; j++) {
+            const size_t o = (size_t)min(tb + j, len - 1) * pitch;
+            c_[j] = pC[o]; u0_[j] = pU0[o];
+            u1_[j] = (R > 1) ? pU1[o] : 0.0f;
         }
-        float o0[PF], o1[PF];
+        float cp, d, f0, f1 = 0.0f;
+        if (k == 0) {
+            cp = lam * c_[0];
+            const float om = 1.0f - cp;
+            d = cp / om;
+            f0 = u0_[0] / om;
+            if (R > 1) f1 = u1_[0] / om;
+        } else {
+            cp = lam * pC[(size_t)(tb - 1) * pitch];
+            const size_t o = (size_t)k * pitch;
+            d = pD[o]; f0 = pF0[o];
+            if (R > 1) f1 = pF1[o];
+        }
 #pragma unroll
-        for (int k = PF - 1; k >= 0; k--) {
-            const int t = t0 + k;
+        for (int j = 0; j < SEG; j++) {
+            if (tb + j < len && (k > 0 || j > 0)) {
+                const float cc = lam * c_[j];
+                const float den = (1.0f - cp - cc) - d * cp;
+                d = cc / den;
+                f0 = (u0_[j] - f0 * cp) / den;
+                if (R > 1) f1 = (u1_[j] - f1 * cp) / den;
+                cp = cc;
+            }
+            c_[j] = d; u0_[j] = f0; u1_[j] = f1;
+        }
+#pragma unroll
+        for (int j = SEG - 1; j >= 0; j--) {
+            const int t = tb + j;
             if (t < len) {
                 const bool last = (t == len - 1);
-                x0 = last ? f0_[k] : f0_[k] - d_[k] * x0;
-                if (R > 1) x1 = last ? f1_[k] : f1_[k] - d_[k] * x1;
+                x0 = last ? u0_[j] : u0_[j] - c_[j] * x0;
+                if (R > 1) x1 = last ? u1_[j] : u1_[j] - c_[j] * x1;
             }
-            o0[k] = x0;
-            o1[k] = x1;
+            u0_[j] = x0;
+            u1_[j] = x1;
         }
 
         if (EPI == EPI_PLANES) {
-            // stage 8 steps of 64 scanlines; flush a 64 x 32 block as 128-byte segments
-            const int col = t0 & (TT - 1);
-            float4* w0 = reinterpret_cast<float4*>(&tile[lane * TPITCH + col]);
-            w0[0] = make_float4(o0[0], o0[1], o0[2], o0[3]);
-            w0[1] = make_float4(o0[4], o0[5], o0[6], o0[7]);
-            if (R > 1) {
-                float4* w1 = reinterpret_cast<float4*>(&tile[64 * TPITCH + lane * TPITCH + col]);
-                w1[0] = make_float4(o1[0], o1[1], o1[2], o1[3]);
-                w1[1] = make_float4(o1[4], o1[5], o1[6], o1[7]);
-            }
-            if (col == 0) {
-                __syncthreads();
-                const int tblk = t0; // first step of the block
-                const int q = lane & 7;
+            // stage the segment of 64 scanlines and flush it as a 64 x 32 block of 128-byte segments
+            float4* w0 = reinterpret_cast<float4*>(&tile[lane * TPITCH]);
 #pragma unroll
-                for (int m = 0; m < 8; m++) {
-                    const int row = m * 8 + (lane >> 3);
-                    const int srow = blockIdx.x * 64 + row;
-                    if (srow < a.nscan) {
-                        const size_t o = pb + (size_t)srow * a.pitch_out + tblk + 4 * q;
-                        *reinterpret_cast<float4*>(a.O0 + o) =
-                            *reinterpret_cast<const float4*>(&tile[row * TPITCH + 4 * q]);
-                        if (R > 1)
-                            *reinterpret_cast<float4*>(a.O1 + o) =
-                                *reinterpret_cast<const float4*>(&tile[64 * TPITCH + row * TPITCH + 4 * q]);
-                    }
-                }
-                __syncthreads();
+            for (int q = 0; q < SEG / 4; q++) w0[q] = make_float4(u0_[4 * q], u0_[4 * q + 1], u0_[4 * q + 2], u0_[4 * q + 3]);
+            if (R > 1) {
+                float4* w1 = reinterpret_cast<float4*>(&tile[64 * TPITCH + lane * TPITCH]);
+#pragma unroll
+                for (int q = 0; q < SEG / 4; q++) w1[q] = make_float4(u1_[4 * q], u1_[4 * q + 1], u1_[4 * q + 2], u1_[4 * q + 3]);
             }
+            __syncthreads();
+            const int q = lane & 7;
+#pragma unroll
+            for (int m = 0; m < 8; m++) {
+                const int row = m * 8 + (lane >> 3);
+                const int srow = blockIdx.x * 64 + row;
+                if (srow < a.nscan) {
+                    const size_t o = pb + (size_t)srow * a.pitch_out + tb + 4 * q;
+                    *reinterpret_cast<float4*>(a.O0 + o) =
+                        *reinterpret_cast<const float4*>(&tile[row * TPITCH + 4 * q]);
+                    if (R > 1)
+                        *reinterpret_cast<float4*>(a.O1 + o) =
+                            *reinterpret_cast<const float4*>(&tile[64 * TPITCH + row * TPITCH + 4 * q]);
+                }
+            }
+            __syncthreads();
         } else {
             // fused epilogue, row-major image: step t = image row, scanline s = image column
             if (s < a.nscan) {
 #pragma unroll
-                for (int k = PF - 1; k >= 0; k--) {
-                    const int t = t0 + k;
+                for (int j = SEG - 1; j >= 0; j--) {
+                    const int t = tb + j;
                     if (t < len) {
                         char* row = reinterpret_cast<char*>(a.out) + (ptrdiff_t)pz * a.out_pair_stride +
                                     (ptrdiff_t)(a.out_y0 + t) * a.out_stride;
                         const size_t e = (size_t)(a.out_x0 + s) * a.out_cn + a.out_c;
                         if (EPI == EPI_WLS_CONF) {
-                            const float rcp = 1.0f / (o1[k] + ADF_EPS);     // DF.cpp:295
-                            reinterpret_cast<int16_t*>(row)[e] = sat16(o0[k] * rcp); // DF.cpp:296
+                            const float rcp = 1.0f / (u1_[j] + ADF_EPS);     // DF.cpp:295
+                            reinterpret_cast<int16_t*>(row)[e] = sat16(u0_[j] * rcp); // DF.cpp:296
                         } else if (EPI == EPI_I16)
-                            reinterpret_cast<int16_t*>(row)[e] = sat16(o0[k]);
+                            reinterpret_cast<int16_t*>(row)[e] = sat16(u0_[j]);
                         else if (EPI == EPI_U8)
-                            reinterpret_cast<uint8_t*>(row)[e] = sat8(o0[k]);
+                            reinterpret_cast<uint8_t*>(row)[e] = sat8(u0_[j]);
                         else
-                            reinterpret_cast<float*>(row)[e] = o0[k];
+                            reinterpret_cast<float*>(row)[e] = u0_[j];
                     }
                 }
             }
@@ -197,7 +215,7 @@ hipError_t launch_exact_pass(const PassArgs& a, int n_rhs, int epilogue, int n_p
 {
     if (a.len < 1 || a.nscan < 1 || n_pairs < 1) return hipErrorInvalidValue;
     if (a.pitch_in % 64 != 0 || a.pitch_in < a.nscan) return hipErrorInvalidValue;
-    if (epilogue == EPI_PLANES && (a.pitch_out % 64 != 0 || a.pitch_out < ((a.len + TT - 1) / TT) * TT))
+    if (epilogue == EPI_PLANES && (a.pitch_out % 64 != 0 || a.pitch_out < ((a.len + SEG - 1) / SEG) * SEG))
         return hipErrorInvalidValue;
     dim3 grid(a.pitch_in / 64, n_pairs), block(64);
 #define ADF_LAUNCH(RR, EE) hipLaunchKernelGGL((exact_pass_kernel<RR, EE>), grid, block, 0, st, a)
