@@ -474,7 +474,8 @@ static int wls_filter_impl(adf_wls_t* h, int n_pairs,
             ProfScope ps(prof, K_FILL, 2.0 * (F - P), 2.0 * (F - P), st);
             HIP_TRY(launch_outside(oa, n, st));
         }
-        WeightArgs wa{gv, sG, psG, gch, (const float*)h->lut.dev.p, p.CH, p.CV, orient_h, orient_cv, g};
+        WeightArgs wa{gv, sG, psG, gch, (const float*)h->lut.dev.p, p.CH, p.CV, orient_h, orient_cv, g,
+                      wave ? nullptr : p.B0};   // exact: B0 is free until the first pass writes its output there
         // confidence mode: the weights depend on the guide only and the confidence kernels on the disparity
         // maps only -- one is bound by memory latency, the others lean on the vector ALUs -- so the weight
         // kernel is forked onto the side stream and joined before the first solve pass
@@ -818,7 +819,8 @@ extern "C" int adf_fgs_create(adf_fgs_t** out, const uint8_t* guide, ptrdiff_t g
         float* base = (float*)f->planes.p;
         WeightArgs wa{(const uint8_t*)f->io.p, (ptrdiff_t)w * gch, 0, gch, (const float*)f->lut.dev.p,
                       base, base + f->g.plane, f->solver == ADF_SOLVER_WAVE ? ORIENT_N : ORIENT_T,
-                      f->solver == ADF_SOLVER_WAVE ? ORIENT_STRIP : ORIENT_N, f->g};
+                      f->solver == ADF_SOLVER_WAVE ? ORIENT_STRIP : ORIENT_N, f->g,
+                      f->solver == ADF_SOLVER_WAVE ? nullptr : base + 5 * f->g.plane};   // B0
         e = launch_weights(wa, 1, st);
     }
     if (e == hipSuccess) e = hipStreamSynchronize(st);

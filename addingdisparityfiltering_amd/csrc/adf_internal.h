@@ -103,6 +103,9 @@ struct WeightArgs {
     const float* lut;
     float* chor; float* cvert; int chor_orient, cvert_orient;
     Geom g;
+    // exact solver (chor_orient == ORIENT_T): a free plane the streaming kernel can write Chor row-major
+    // into before it is transposed; null = the generic tile kernel writes the transposed plane itself
+    float* scratch;
 };
 
 // One solve pass (forward elimination + back substitution along every scanline).

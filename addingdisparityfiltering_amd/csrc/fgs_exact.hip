@@ -37,7 +37,9 @@ namespace adf {
 namespace {
 
 constexpr int PF = 8;        // steps per software-pipelined chunk of the forward sweep (loads run one chunk ahead)
-constexpr int SEG = 32;      // steps per checkpointed segment = steps per transposed output block (128-byte segments)
+constexpr int SEG = 16;      // steps per checkpointed segment (its D and right-hand sides live in registers)
+constexpr int TT = 32;       // steps per transposed output block (128-byte segments)
+static_assert(TT == 2 * SEG, "a transposed output block is two segments");
 constexpr int TPITCH = 36;   // LDS tile row pitch in floats: 16-byte aligned, conflict-free b128
 
 template <int R, int EPI>
@@ -107,8 +109,13 @@ __global__ void __launch_bounds__(64) exact_pass_kernel(PassArgs a)
     }
 
     // ------------------------- back substitution, one recomputed segment at a time -------------------------
-    __shared__ __align__(16) float tile[(EPI == EPI_PLANES) ? R * 64 * TPITCH : 4];
+    // one 64 x 32 tile, used by the right-hand sides one after the other: 9 KB per wavefront keeps four
+    // wavefronts per SIMD resident (the whole row pass of a 4K batch is then a single round of waves)
+    __shared__ __align__(16) float tile[(EPI == EPI_PLANES) ? 64 * TPITCH : 4];
     float x0 = 0.0f, x1 = 0.0f;
+    float hi0[SEG], hi1[SEG];   // solved upper half of the current output block (EPI_PLANES)
+#pragma unroll
+    for (int j = 0; j < SEG; j++) { hi0[j] = 0.0f; hi1[j] = 0.0f; }
     const int nseg = (len + SEG - 1) / SEG;
     for (int k = nseg - 1; k >= 0; k--) {
         const int tb = k * SEG;
@@ -158,31 +165,38 @@ __global__ void __launch_bounds__(64) exact_pass_kernel(PassArgs a)
         }
 
         if (EPI == EPI_PLANES) {
-            // stage the segment of 64 scanlines and flush it as a 64 x 32 block of 128-byte segments
-            float4* w0 = reinterpret_cast<float4*>(&tile[lane * TPITCH]);
+            // stage the segment of 64 scanlines; flush a 64 x 32 block of 128-byte segments once its
+            // lowest segment is done (segments arrive in descending order)
+            // A transposed output block is TT = 2 * SEG steps: the upper segment (processed first) waits in
+            // registers until the lower one is solved, then each right-hand side goes through the tile.
+            if ((tb & (TT - 1)) != 0) {
 #pragma unroll
-            for (int q = 0; q < SEG / 4; q++) w0[q] = make_float4(u0_[4 * q], u0_[4 * q + 1], u0_[4 * q + 2], u0_[4 * q + 3]);
-            if (R > 1) {
-                float4* w1 = reinterpret_cast<float4*>(&tile[64 * TPITCH + lane * TPITCH]);
+                for (int j = 0; j < SEG; j++) { hi0[j] = u0_[j]; hi1[j] = u1_[j]; }
+            } else {
 #pragma unroll
-                for (int q = 0; q < SEG / 4; q++) w1[q] = make_float4(u1_[4 * q], u1_[4 * q + 1], u1_[4 * q + 2], u1_[4 * q + 3]);
-            }
-            __syncthreads();
-            const int q = lane & 7;
+                for (int r = 0; r < R; r++) {
+                    float4* w = reinterpret_cast<float4*>(&tile[lane * TPITCH]);
 #pragma unroll
-            for (int m = 0; m < 8; m++) {
-                const int row = m * 8 + (lane >> 3);
-                const int srow = blockIdx.x * 64 + row;
-                if (srow < a.nscan) {
-                    const size_t o = pb + (size_t)srow * a.pitch_out + tb + 4 * q;
-                    *reinterpret_cast<float4*>(a.O0 + o) =
-                        *reinterpret_cast<const float4*>(&tile[row * TPITCH + 4 * q]);
-                    if (R > 1)
-                        *reinterpret_cast<float4*>(a.O1 + o) =
-                            *reinterpret_cast<const float4*>(&tile[64 * TPITCH + row * TPITCH + 4 * q]);
+                    for (int q = 0; q < SEG / 4; q++) {
+                        w[q] = r == 0 ? make_float4(u0_[4 * q], u0_[4 * q + 1], u0_[4 * q + 2], u0_[4 * q + 3])
+                                      : make_float4(u1_[4 * q], u1_[4 * q + 1], u1_[4 * q + 2], u1_[4 * q + 3]);
+                        w[SEG / 4 + q] = r == 0 ? make_float4(hi0[4 * q], hi0[4 * q + 1], hi0[4 * q + 2], hi0[4 * q + 3])
+                                                : make_float4(hi1[4 * q], hi1[4 * q + 1], hi1[4 * q + 2], hi1[4 * q + 3]);
+                    }
+                    __syncthreads();
+                    float* O = r == 0 ? a.O0 : a.O1;
+                    const int q = lane & 7;
+#pragma unroll
+                    for (int m = 0; m < 8; m++) {
+                        const int row = m * 8 + (lane >> 3);
+                        const int srow = blockIdx.x * 64 + row;
+                        if (srow < a.nscan)
+                            *reinterpret_cast<float4*>(O + pb + (size_t)srow * a.pitch_out + tb + 4 * q) =
+                                *reinterpret_cast<const float4*>(&tile[row * TPITCH + 4 * q]);
+                    }
+                    __syncthreads();
                 }
             }
-            __syncthreads();
         } else {
             // fused epilogue, row-major image: step t = image row, scanline s = image column
             if (s < a.nscan) {
@@ -215,7 +229,7 @@ hipError_t launch_exact_pass(const PassArgs& a, int n_rhs, int epilogue, int n_p
 {
     if (a.len < 1 || a.nscan < 1 || n_pairs < 1) return hipErrorInvalidValue;
     if (a.pitch_in % 64 != 0 || a.pitch_in < a.nscan) return hipErrorInvalidValue;
-    if (epilogue == EPI_PLANES && (a.pitch_out % 64 != 0 || a.pitch_out < ((a.len + SEG - 1) / SEG) * SEG))
+    if (epilogue == EPI_PLANES && (a.pitch_out % 64 != 0 || a.pitch_out < ((a.len + TT - 1) / TT) * TT))
         return hipErrorInvalidValue;
     dim3 grid(a.pitch_in / 64, n_pairs), block(64);
 #define ADF_LAUNCH(RR, EE) hipLaunchKernelGGL((exact_pass_kernel<RR, EE>), grid, block, 0, st, a)

@@ -210,10 +210,48 @@ __global__ void __launch_bounds__(NT) weights_stream_kernel(WeightArgs a)
     }
 }
 
+// Row-major [rh][pw] -> transposed [rw][ph] through a 64 x 64 LDS tile, 16-byte accesses on both sides
+// (pw and ph are multiples of 64).  Rows past rh are not part of the source plane: they become zeros.
+__global__ void __launch_bounds__(256) transpose_n_to_t_kernel(const float* __restrict__ src, float* __restrict__ dst, Geom g)
+{
+    __shared__ float tile[64][65];
+    const int tid = threadIdx.x;
+    const int j0 = blockIdx.x * 64, i0 = blockIdx.y * 64;
+    const size_t pb = (size_t)blockIdx.z * g.plane;
+    const int c4 = tid & 15, r = tid >> 4;
+#pragma unroll
+    for (int m = 0; m < 4; m++) {
+        const int row = r + 16 * m;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (i0 + row < g.rh) v = *reinterpret_cast<const float4*>(src + pb + (size_t)(i0 + row) * g.pw + j0 + 4 * c4);
+        tile[row][4 * c4 + 0] = v.x; tile[row][4 * c4 + 1] = v.y; tile[row][4 * c4 + 2] = v.z; tile[row][4 * c4 + 3] = v.w;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int m = 0; m < 4; m++) {
+        const int col = r + 16 * m;
+        if (j0 + col < g.rw) {
+            const float4 v = make_float4(tile[4 * c4 + 0][col], tile[4 * c4 + 1][col], tile[4 * c4 + 2][col], tile[4 * c4 + 3][col]);
+            *reinterpret_cast<float4*>(dst + pb + (size_t)(j0 + col) * g.ph + i0 + 4 * c4) = v;
+        }
+    }
+}
+
 } // namespace
 
 hipError_t launch_weights(const WeightArgs& a, int n_pairs, hipStream_t st)
 {
+    if (a.chor_orient == ORIENT_T && a.cvert_orient == ORIENT_N && a.scratch) {
+        // exact solver: the streaming kernel (one pass over the guide at streaming speed) + one tiled
+        // transpose of Chor beat the generic tile kernel's scattered look-ups by 3x
+        WeightArgs b = a;
+        b.chor = a.scratch; b.chor_orient = ORIENT_N; b.scratch = nullptr;
+        hipError_t e = launch_weights(b, n_pairs, st);
+        if (e != hipSuccess) return e;
+        dim3 grid(a.g.pw / 64, a.g.ph / 64, n_pairs);
+        hipLaunchKernelGGL(transpose_n_to_t_kernel, grid, dim3(256), 0, st, a.scratch, a.chor, a.g);
+        return hipGetLastError();
+    }
     if (a.cvert_orient != ORIENT_N && !(a.cvert_orient == ORIENT_STRIP && a.chor_orient == ORIENT_N)) return hipErrorInvalidValue;
     if (a.chor_orient == ORIENT_N) {   // wave solver: streaming kernel
         dim3 sgrid((a.g.rw + NT - 1) / NT, 1, n_pairs);
