@@ -18,10 +18,12 @@ import addingdisparityfiltering_amd as adf  # noqa: E402
 from addingdisparityfiltering_amd import _lib, synthetic  # noqa: E402
 
 
-def main(pairs=64):
+def main(pairs=64, width=None):
     dev = torch.device("cuda:0")
     cfg = synthetic.CONFIGS[3]
     roi, radius = cfg["roi"], cfg["radius"]
+    if width:   # narrower ROI = fewer strips = fewer CUs loading at once
+        roi = (roi[0], roi[1], int(width), roi[3])
     view, dl, dr = synthetic.make_artificial_batch_torch(pairs, cfg["W"], cfg["H"], cfg["channels"], synthetic.seed_for(3, 0),
                                                          cfg["rect_disparity"], dev)
     f = adf.createDisparityWLSFilterGeneric(True)
@@ -65,4 +67,4 @@ def main(pairs=64):
 
 
 if __name__ == "__main__":
-    main(int(sys.argv[1]) if len(sys.argv) > 1 else 64)
+    main(int(sys.argv[1]) if len(sys.argv) > 1 else 64, int(sys.argv[2]) if len(sys.argv) > 2 else None)
