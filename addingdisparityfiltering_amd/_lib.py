@@ -70,6 +70,7 @@ SYMBOLS = [
     ("adf_fgs_create", _i, [C.POINTER(_vp), _vp, _pd, _i, _i, _i, _d, _d, _d, _i, _i]),
     ("adf_fgs_destroy", None, [_vp]),
     ("adf_fgs_filter_host", _i, [_vp, _vp, _pd, _vp, _pd, _i, _i]),
+    ("adf_fgs_filter_device", _i, [_vp, _vp, _pd, _vp, _pd, _i, _i, _vp]),
     ("adf_compute_mse_host", _i, [_vp, _pd, _vp, _pd, _i, _i, C.POINTER(Rect), C.POINTER(_d)]),
     ("adf_compute_mse_device", _i, [_vp, _pd, _vp, _pd, _i, _i, C.POINTER(Rect), C.POINTER(_d), _vp]),
     ("adf_compute_bad_pixel_percent_host", _i, [_vp, _pd, _vp, _pd, _i, _i, C.POINTER(Rect), _i, C.POINTER(_d)]),

@@ -837,29 +837,17 @@ extern "C" void adf_fgs_destroy(adf_fgs_t* f)
     delete f;
 }
 
-extern "C" int adf_fgs_filter_host(adf_fgs_t* f, const void* src, ptrdiff_t sstride, void* dst, ptrdiff_t dstride,
-                                   int depth, int channels)
+// FastGlobalSmootherFilter::filter on an image staged in f->io (FGS.cpp:200-221: channels one by one).
+static int fgs_filter_staged(adf_fgs* f, int depth, int channels, size_t rowb, hipStream_t st)
 {
-    NEED_HANDLE(f);
-    // FGS.cpp:184
-    if (!src || !dst) return fail(ADF_EBADARG, "src/dst is empty");
-    if (depth != ADF_8U && depth != ADF_16S && depth != ADF_32F) return fail(ADF_EBADARG, "src depth must be CV_8U, CV_16S or CV_32F");
-    if (channels < 1 || channels > 4) return fail(ADF_EBADARG, "src must have 1..4 channels");
-    const size_t esz = depth == ADF_8U ? 1 : depth == ADF_16S ? 2 : 4;
-    const size_t rowb = (size_t)f->w * channels * esz;
-    if (sstride < (ptrdiff_t)rowb || dstride < (ptrdiff_t)rowb)
-        return fail(ADF_ESIZE, "Size of the filtered image must be equal to the size of the guide image"); // FGS.cpp:187
-    DeviceScope ds(f->device);
-    hipStream_t st = nullptr;
     char* img = (char*)f->io.p;
-    HIP_TRY(hipMemcpy2DAsync(img, rowb, src, sstride, rowb, f->h, hipMemcpyHostToDevice, st));
     float* base = (float*)f->planes.p;
     const Geom& g = f->g;
     SolvePlanes p{};
     p.CH = base; p.CV = base + g.plane; p.D = base + 2 * g.plane; p.F0 = base + 3 * g.plane;
     p.A0 = base + 4 * g.plane; p.B0 = base + 5 * g.plane;
     const int epi = depth == ADF_8U ? EPI_U8 : depth == ADF_16S ? EPI_I16 : EPI_F32;
-    for (int c = 0; c < channels; c++) { // FGS.cpp:200-221: channels filtered one by one
+    for (int c = 0; c < channels; c++) {
         const bool wave = f->solver == ADF_SOLVER_WAVE;
         PlainPrologueArgs pa{img, (ptrdiff_t)rowb, 0, depth, channels, c, p.A0, g, wave ? ORIENT_N : ORIENT_T};
         HIP_TRY(launch_plain_prologue(pa, 1, st));
@@ -870,7 +858,50 @@ extern "C" int adf_fgs_filter_host(adf_fgs_t* f, const void* src, ptrdiff_t sstr
                       : run_passes_exact(g, p, 1, f->lambda, f->atten, f->num_iter, fo, 1, st);
         if (rc) return rc;
     }
-    HIP_TRY(hipMemcpy2DAsync(dst, dstride, img, rowb, rowb, f->h, hipMemcpyDeviceToHost, st));
+    return ADF_OK;
+}
+
+static int fgs_check_args(adf_fgs* f, const void* src, ptrdiff_t sstride, void* dst, ptrdiff_t dstride, int depth,
+                          int channels, size_t* rowb)
+{
+    // FGS.cpp:184
+    if (!src || !dst) return fail(ADF_EBADARG, "src/dst is empty");
+    if (depth != ADF_8U && depth != ADF_16S && depth != ADF_32F) return fail(ADF_EBADARG, "src depth must be CV_8U, CV_16S or CV_32F");
+    if (channels < 1 || channels > 4) return fail(ADF_EBADARG, "src must have 1..4 channels");
+    const size_t esz = depth == ADF_8U ? 1 : depth == ADF_16S ? 2 : 4;
+    *rowb = (size_t)f->w * channels * esz;
+    if (sstride < (ptrdiff_t)*rowb || dstride < (ptrdiff_t)*rowb)
+        return fail(ADF_ESIZE, "Size of the filtered image must be equal to the size of the guide image"); // FGS.cpp:187
+    return ADF_OK;
+}
+
+extern "C" int adf_fgs_filter_host(adf_fgs_t* f, const void* src, ptrdiff_t sstride, void* dst, ptrdiff_t dstride,
+                                   int depth, int channels)
+{
+    NEED_HANDLE(f);
+    size_t rowb = 0;
+    int rc = fgs_check_args(f, src, sstride, dst, dstride, depth, channels, &rowb);
+    if (rc) return rc;
+    DeviceScope ds(f->device);
+    hipStream_t st = nullptr;
+    HIP_TRY(hipMemcpy2DAsync(f->io.p, rowb, src, sstride, rowb, f->h, hipMemcpyHostToDevice, st));
+    if ((rc = fgs_filter_staged(f, depth, channels, rowb, st))) return rc;
+    HIP_TRY(hipMemcpy2DAsync(dst, dstride, f->io.p, rowb, rowb, f->h, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
+    return ADF_OK;
+}
+
+extern "C" int adf_fgs_filter_device(adf_fgs_t* f, const void* src, ptrdiff_t sstride, void* dst, ptrdiff_t dstride,
+                                     int depth, int channels, void* stream)
+{
+    NEED_HANDLE(f);
+    size_t rowb = 0;
+    int rc = fgs_check_args(f, src, sstride, dst, dstride, depth, channels, &rowb);
+    if (rc) return rc;
+    DeviceScope ds(f->device);
+    hipStream_t st = (hipStream_t)stream;
+    HIP_TRY(hipMemcpy2DAsync(f->io.p, rowb, src, sstride, rowb, f->h, hipMemcpyDeviceToDevice, st));
+    if ((rc = fgs_filter_staged(f, depth, channels, rowb, st))) return rc;
+    HIP_TRY(hipMemcpy2DAsync(dst, dstride, f->io.p, rowb, rowb, f->h, hipMemcpyDeviceToDevice, st));
     return ADF_OK;
 }

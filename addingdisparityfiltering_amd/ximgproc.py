@@ -396,7 +396,10 @@ class FastGlobalSmootherFilter:
                 pass
 
     def filter(self, src, dst=None):
-        """EF.hpp:370, FGS.cpp:182-233."""
+        """EF.hpp:370, FGS.cpp:182-233.  A torch CUDA tensor is filtered where it is (asynchronously on
+        torch's current stream) and a CUDA tensor is returned; anything else takes the host path."""
+        if _is_torch(src) and src.is_cuda:
+            return self._filter_device(src, dst)
         s = np.ascontiguousarray(src)
         depth = {np.dtype(np.uint8): _lib.DEPTH_8U, np.dtype(np.int16): _lib.DEPTH_16S,
                  np.dtype(np.float32): _lib.DEPTH_32F}.get(s.dtype)
@@ -413,6 +416,28 @@ class FastGlobalSmootherFilter:
         rowb = s.shape[1] * cn * s.itemsize
         _lib.check(_lib.lib().adf_fgs_filter_host(self._h, C.c_void_p(s.ctypes.data), rowb,
                                                   C.c_void_p(dst.ctypes.data), rowb, depth, cn))
+        return dst
+
+
+    def _filter_device(self, src, dst):
+        depth = {torch.uint8: _lib.DEPTH_8U, torch.int16: _lib.DEPTH_16S, torch.float32: _lib.DEPTH_32F}.get(src.dtype)
+        if depth is None or src.dim() not in (2, 3):
+            raise AdfError(_lib.ADF_EBADARG, "src depth must be CV_8U, CV_16S or CV_32F")  # FGS.cpp:184
+        s = src.contiguous()
+        cn = 1 if s.dim() == 2 else s.shape[2]
+        if cn > 4:
+            raise AdfError(_lib.ADF_EBADARG, "src must have at most 4 channels")
+        if tuple(s.shape[:2]) != tuple(self._shape):
+            raise AdfError(_lib.ADF_ESIZE,
+                           "Size of the filtered image must be equal to the size of the guide image")  # FGS.cpp:187
+        if dst is None:
+            dst = torch.empty_like(s)
+        elif not (_is_torch(dst) and dst.is_cuda and dst.is_contiguous() and dst.shape == s.shape and dst.dtype == s.dtype):
+            raise AdfError(_lib.ADF_EBADARG, "dst must be a contiguous CUDA tensor shaped like src")
+        rowb = s.shape[1] * cn * s.element_size()
+        st = C.c_void_p(torch.cuda.current_stream(s.device).cuda_stream)
+        _lib.check(_lib.lib().adf_fgs_filter_device(self._h, C.c_void_p(s.data_ptr()), rowb,
+                                                    C.c_void_p(dst.data_ptr()), rowb, depth, cn, st))
         return dst
 
 

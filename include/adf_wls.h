@@ -188,6 +188,11 @@ void adf_fgs_destroy(adf_fgs_t* h);
  * 1..4 interleaved channels; dst may alias src. */
 int adf_fgs_filter_host(adf_fgs_t* h, const void* src, ptrdiff_t src_stride, void* dst,
                         ptrdiff_t dst_stride, int depth, int channels);
+/* The same with DEVICE pointers, asynchronous on `stream` (a hipStream_t; NULL = the null
+ * stream): for callers whose images already live in HBM (EdgeAwareInterpolator-style flow
+ * post-filtering, sparse_match_interpolators.cpp:202-203).  dst may alias src. */
+int adf_fgs_filter_device(adf_fgs_t* h, const void* src, ptrdiff_t src_stride, void* dst,
+                          ptrdiff_t dst_stride, int depth, int channels, void* stream);
 
 /* ---------------- evaluation utilities (DF.hpp:163-204) ---------------- */
 

@@ -194,6 +194,29 @@ def test_generic_fgs_api(adf, oracle, dt, cn, gch):
     assert got.dtype == src.dtype and np.array_equal(got, exp)
 
 
+@pytest.mark.parametrize("dt,cn", [(np.uint8, 3), (np.int16, 1), (np.float32, 2)])
+def test_generic_fgs_device_pointers(adf, oracle, dt, cn):
+    """adf_fgs_filter_device: the same filter on images that already live in HBM (torch CUDA tensors are
+    passed by pointer on torch's current stream); dst may alias src."""
+    import torch
+    rng = np.random.default_rng(77 + cn)
+    h, w = 97, 203
+    guide = rng.integers(0, 255, (h, w, 3), dtype=np.uint8)
+    shape = (h, w) if cn == 1 else (h, w, cn)
+    if dt == np.float32: src = rng.uniform(-1e3, 1e3, shape).astype(np.float32)
+    elif dt == np.int16: src = rng.integers(-32767, 32767, shape).astype(np.int16)
+    else: src = rng.integers(0, 255, shape).astype(np.uint8)
+    exp = oracle.fgs_filter(guide, src, 500.0, 1.5, threads=4)      # EdgeAwareInterpolator's settings
+    f = adf.createFastGlobalSmootherFilter(guide, 500.0, 1.5)
+    t = torch.from_numpy(src).cuda()
+    got = f.filter(t)
+    assert got.is_cuda and got.dtype == t.dtype
+    assert np.array_equal(got.cpu().numpy(), exp)
+    f.filter(t, t)                                                  # in place
+    assert np.array_equal(t.cpu().numpy(), exp)
+    assert np.array_equal(f.filter(src), exp)                       # host path, same handle
+
+
 def test_error_behaviour(adf):
     """CV_Assert / CV_Error sites of DF.cpp:221-222,262-264 and FGS.cpp:143-144,184-189 -> AdfError."""
     view, dl, dr, roi = synthetic.make_artificial_example(64, 48, 3, seed=1)
