@@ -101,10 +101,21 @@ def main():
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # ADF_BENCH_BACKEND=gloo is a rehearsal mode for one-GPU boxes: the ranks share the visible GPUs
+    # (rank r uses device r % device_count) and the two scalar all-reduces run on CPU tensors, so the whole
+    # N > 1 flow executes except RCCL itself.  The driver's runs use the default, nccl (= RCCL).
+    backend = os.environ.get("ADF_BENCH_BACKEND", "nccl")
+    dev_index = local_rank if backend == "nccl" else local_rank % max(1, torch.cuda.device_count())
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
+    coll_dev = dev if backend == "nccl" else torch.device("cpu")
     if world > 1:
-        dist.init_process_group(backend="nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=dev)
+        else:
+            if args.distribution == "scatter":
+                raise SystemExit("the scatter distribution moves device tensors: it needs the nccl backend")
+            dist.init_process_group(backend=backend)
 
     cfg = synthetic.CONFIGS[args.config]
     W, H, roi, ch, radius = cfg["W"], cfg["H"], cfg["roi"], cfg["channels"], cfg["radius"]
@@ -176,7 +187,7 @@ def main():
     if world > 1:
         dist.barrier()
     elapsed = time.perf_counter() - t0
-    elapsed = parallel.max_over_ranks(elapsed, dev)
+    elapsed = parallel.max_over_ranks(elapsed, coll_dev)
     prof = f.readProfile()
     f.enableProfiling(False)
 
@@ -189,7 +200,7 @@ def main():
         torch.cuda.synchronize(); dist.barrier()
         gather_ms = (time.perf_counter() - t1) * 1e3
         del full_out
-    checksum = parallel.sum_over_ranks(float(out.to(torch.int64).sum().item()), dev)
+    checksum = parallel.sum_over_ranks(float(out.to(torch.int64).sum().item()), coll_dev)
 
     if rank != 0:
         if world > 1:
