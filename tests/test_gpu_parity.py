@@ -151,6 +151,32 @@ def test_batch_equals_singles_and_strided_inputs(adf, oracle):
     assert int(big_o[:, :, w:].abs().sum()) == 0                 # nothing written past the row
 
 
+@pytest.mark.parametrize("solver", ["exact", "wave"])
+def test_workspace_limit_chunks_the_batch(adf, monkeypatch, solver):
+    """A batch that does not fit ADF_WS_LIMIT_GB is filtered in chunks of pairs through the same planes
+    (adf_api.hip: chunk loop, one weight-kernel fork / join per chunk): same bits as the unchunked call,
+    and getConfidenceMap still serves every pair."""
+    n, w, h = 5, 200, 90
+    pairs = [synthetic.make_artificial_example(w, h, 3, seed=300 + k) for k in range(n)]
+    roi = pairs[0][3]
+    view = np.stack([p[0] for p in pairs]); dl = np.stack([p[1] for p in pairs]); dr = np.stack([p[2] for p in pairs])
+    sv = adf.SOLVER_WAVE if solver == "wave" else adf.SOLVER_EXACT
+
+    def run():
+        f = adf.createDisparityWLSFilterGeneric(True)
+        f.setSolver(sv); f.setSigmaColor(1.5)
+        out = f.filter(dl, view, None, dr, roi)
+        return out, [np.array(f.getConfidenceMap(k)) for k in range(n)], f.workspaceBytes()
+
+    ref, ref_conf, ws_full = run()
+    monkeypatch.setenv("ADF_WS_LIMIT_GB", "%.9f" % (2.2 * ws_full / n / 2 ** 30))   # room for two pairs at a time
+    got, got_conf, ws_small = run()
+    assert ws_small < ws_full
+    assert np.array_equal(got, ref)
+    for a, b in zip(got_conf, ref_conf):
+        assert np.array_equal(a, b)
+
+
 def test_full_4k_pair_bit_exact(adf, oracle):
     """BASELINE config 3 geometry (3840x2160, ROI 256..3840), one pair, full size."""
     view, dl, dr, roi, radius = synthetic.make_config_example(3)
