@@ -847,16 +847,23 @@ static int fgs_filter_staged(adf_fgs* f, int depth, int channels, size_t rowb, h
     p.CH = base; p.CV = base + g.plane; p.D = base + 2 * g.plane; p.F0 = base + 3 * g.plane;
     p.A0 = base + 4 * g.plane; p.B0 = base + 5 * g.plane;
     const int epi = depth == ADF_8U ? EPI_U8 : depth == ADF_16S ? EPI_I16 : EPI_F32;
-    for (int c = 0; c < channels; c++) {
-        const bool wave = f->solver == ADF_SOLVER_WAVE;
-        PlainPrologueArgs pa{img, (ptrdiff_t)rowb, 0, depth, channels, c, p.A0, g, wave ? ORIENT_N : ORIENT_T};
+    const bool wave = f->solver == ADF_SOLVER_WAVE;
+    for (int c = 0; c < channels;) {
+        // The reference filters the channels one by one with the same weights (FGS.cpp:200-221); the wave
+        // solver takes them two at a time as the two right-hand sides of one factorisation (its pair plane
+        // spans A0 and B0, which are adjacent) -- the same arithmetic per channel, half the passes.
+        const int nr = (wave && c + 1 < channels) ? 2 : 1;
+        PlainPrologueArgs pa{img, (ptrdiff_t)rowb, 0, depth, channels, c, p.A0, g,
+                             wave ? (nr == 2 ? ORIENT_PAIR : ORIENT_N) : ORIENT_T};
+        pa.pair2 = nr == 2; pa.c2 = c + 1;
         HIP_TRY(launch_plain_prologue(pa, 1, st));
         // the epilogue of channel c overwrites only channel c of the staged image, which later
         // channels never read (they read their own channel), so filtering in place is safe
         FinalOut fo{epi, img, (ptrdiff_t)rowb, 0, 0, 0, channels, c};
-        int rc = wave ? run_passes_wave(g, p, 1, f->lambda, f->atten, f->num_iter, fo, 1, st)
+        int rc = wave ? run_passes_wave(g, p, nr, f->lambda, f->atten, f->num_iter, fo, 1, st)
                       : run_passes_exact(g, p, 1, f->lambda, f->atten, f->num_iter, fo, 1, st);
         if (rc) return rc;
+        c += nr;
     }
     return ADF_OK;
 }

@@ -88,6 +88,9 @@ struct PlainPrologueArgs {
     // optional confidence weighting (down-scaled path, DF.cpp:286-290 on the resized maps):
     // U0 = conf*float(src), U1 = conf, conf read from a full-frame plane of pitch g.W
     const float* conf; float* U1;
+    // or a second source channel as the second right-hand side (generic FGS on the wave solver: channel
+    // pairs share one factorisation): U1 = float(src channel c2) when pair2 is set (conf must be null)
+    int pair2, c2;
 };
 
 // cv::resize(INTER_LINEAR) of CV_16SC1 (is16, optional saturating post-scale) or CV_32FC1 images.

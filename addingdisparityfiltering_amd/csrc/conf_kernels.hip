@@ -452,7 +452,8 @@ __global__ void __launch_bounds__(NT) plain_prologue_kernel(PlainPrologueArgs a)
     const float* cf = a.conf ? a.conf + pz * g.frame : nullptr;
     const bool pair = a.orient == ORIENT_PAIR;          // only with confidence weighting (two right-hand sides)
     float* U0 = a.U0 + pz * (pair ? 2 : 1) * g.plane;
-    float* U1 = a.conf ? (pair ? U0 + ADF_STRIP : a.U1 + pz * g.plane) : nullptr;
+    const bool two = a.conf != nullptr || a.pair2;      // two right-hand sides
+    float* U1 = two ? (pair ? U0 + ADF_STRIP : a.U1 + pz * g.plane) : nullptr;
     const int j = x0 + tx;
 #pragma unroll
     for (int kk = 0; kk < TY / 4; kk++) {
@@ -465,6 +466,12 @@ __global__ void __launch_bounds__(NT) plain_prologue_kernel(PlainPrologueArgs a)
             if (a.depth == 3) u0 = (float)reinterpret_cast<const int16_t*>(row)[e];      // CV_16S
             else if (a.depth == 0) u0 = (float)reinterpret_cast<const uint8_t*>(row)[e]; // CV_8U
             else u0 = reinterpret_cast<const float*>(row)[e];                            // CV_32F
+            if (a.pair2) {                                                               // second channel, FGS.cpp:200-205
+                const size_t e2 = (size_t)(g.rx + j) * a.cn + a.c2;
+                if (a.depth == 3) u1 = (float)reinterpret_cast<const int16_t*>(row)[e2];
+                else if (a.depth == 0) u1 = (float)reinterpret_cast<const uint8_t*>(row)[e2];
+                else u1 = reinterpret_cast<const float*>(row)[e2];
+            }
             if (cf) {                                                                    // DF.cpp:286-290
                 u1 = cf[(size_t)(g.ry + i) * g.W + g.rx + j];
                 u0 = u1 * u0;
@@ -473,7 +480,7 @@ __global__ void __launch_bounds__(NT) plain_prologue_kernel(PlainPrologueArgs a)
         if (a.orient != ORIENT_T) {
             if (ok) {
                 const size_t o = pair ? pair_index(i, j, g.pw) : (size_t)i * g.pw + j;
-                U0[o] = u0; if (cf) U1[o] = u1;
+                U0[o] = u0; if (two) U1[o] = u1;
             }
         } else {
             t0[tx * (TY + 1) + ty + 4 * kk] = u0;
@@ -488,7 +495,7 @@ __global__ void __launch_bounds__(NT) plain_prologue_kernel(PlainPrologueArgs a)
             const int jj = x0 + cidx, ii = y0 + ridx;
             if (jj < g.rw && ii < g.rh) {
                 U0[(size_t)jj * g.ph + ii] = t0[cidx * (TY + 1) + ridx];
-                if (cf) U1[(size_t)jj * g.ph + ii] = t1[cidx * (TY + 1) + ridx];
+                if (two) U1[(size_t)jj * g.ph + ii] = t1[cidx * (TY + 1) + ridx];
             }
         }
     }

@@ -206,12 +206,18 @@ __global__ void __launch_bounds__(VT) wave_vpass_kernel(WavePassArgs a)
                             if (EPI == EPI_WLS_CONF) {
                                 const float rcp = 1.0f / (f1[i][e] + ADF_EPS);             // DF.cpp:295
                                 *reinterpret_cast<int16_t*>(dst) = sat16(f0[i][e] * rcp);  // DF.cpp:296
-                            } else if (EPI == EPI_I16)
-                                *reinterpret_cast<int16_t*>(dst) = sat16(f0[i][e]);
-                            else if (EPI == EPI_U8)
-                                *reinterpret_cast<uint8_t*>(dst) = sat8(f0[i][e]);
-                            else
-                                *reinterpret_cast<float*>(dst) = f0[i][e];
+                            } else {
+                                // generic FGS (FGS.cpp:216-218): with two right-hand sides the second one is
+                                // the next interleaved channel of the same image
+#pragma unroll
+                                for (int r = 0; r < R; r++) {
+                                    const float x = r ? f1[i][e] : f0[i][e];
+                                    char* d = dst + r * esz;
+                                    if (EPI == EPI_I16) *reinterpret_cast<int16_t*>(d) = sat16(x);
+                                    else if (EPI == EPI_U8) *reinterpret_cast<uint8_t*>(d) = sat8(x);
+                                    else *reinterpret_cast<float*>(d) = x;
+                                }
+                            }
                         }
                     }
                 }
@@ -233,6 +239,9 @@ hipError_t launch_v(const WavePassArgs& a, int n_rhs, int epi, int n_pairs, hipS
     else if (n_rhs == 1 && epi == EPI_I16) ADF_LV(1, EPI_I16);
     else if (n_rhs == 1 && epi == EPI_F32) ADF_LV(1, EPI_F32);
     else if (n_rhs == 1 && epi == EPI_U8) ADF_LV(1, EPI_U8);
+    else if (n_rhs == 2 && epi == EPI_I16) ADF_LV(2, EPI_I16);   // channel pairs of a generic FGS source
+    else if (n_rhs == 2 && epi == EPI_F32) ADF_LV(2, EPI_F32);
+    else if (n_rhs == 2 && epi == EPI_U8) ADF_LV(2, EPI_U8);
     else return hipErrorInvalidValue;
 #undef ADF_LV
     return hipGetLastError();
