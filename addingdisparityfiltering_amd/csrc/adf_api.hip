@@ -266,8 +266,8 @@ struct adf_wls {
     float roll_off = 0.001f;
     // EF.hpp:393 defaults used by DF.cpp:292
     double atten = 0.25; int num_iter = 3;
-    int solver = ADF_SOLVER_EXACT;
-    int last_solver = ADF_SOLVER_EXACT;
+    int solver = ADF_SOLVER_WAVE;      // default: the throughput path (see include/adf_wls.h)
+    int last_solver = ADF_SOLVER_WAVE;
     // state of the last call
     adf_rect roi{0, 0, 0, 0};
     int last_W = 0, last_H = 0, last_pairs = 0;

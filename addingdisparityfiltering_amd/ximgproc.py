@@ -374,7 +374,7 @@ def createDisparityWLSFilterGeneric(use_confidence):
 # Fast Global Smoother (EF.hpp:361-413)
 # ---------------------------------------------------------------------------------------------
 class FastGlobalSmootherFilter:
-    def __init__(self, guide, lambda_, sigma_color, lambda_attenuation=0.25, num_iter=3, solver=SOLVER_EXACT):
+    def __init__(self, guide, lambda_, sigma_color, lambda_attenuation=0.25, num_iter=3, solver=SOLVER_WAVE):
         if guide is None or getattr(guide, "size", 0) == 0:
             raise AdfError(_lib.ADF_EBADARG, "guide is empty")  # FGS.cpp:143
         g = np.ascontiguousarray(guide)
@@ -441,14 +441,15 @@ class FastGlobalSmootherFilter:
         return dst
 
 
-def createFastGlobalSmootherFilter(guide, lambda_, sigma_color, lambda_attenuation=0.25, num_iter=3):
-    """EF.hpp:393."""
-    return FastGlobalSmootherFilter(guide, lambda_, sigma_color, lambda_attenuation, num_iter)
+def createFastGlobalSmootherFilter(guide, lambda_, sigma_color, lambda_attenuation=0.25, num_iter=3, solver=SOLVER_WAVE):
+    """EF.hpp:393 (`solver` is this library's extension: SOLVER_WAVE or the bit-exact SOLVER_EXACT)."""
+    return FastGlobalSmootherFilter(guide, lambda_, sigma_color, lambda_attenuation, num_iter, solver)
 
 
-def fastGlobalSmootherFilter(guide, src, lambda_, sigma_color, lambda_attenuation=0.25, num_iter=3, dst=None):
+def fastGlobalSmootherFilter(guide, src, lambda_, sigma_color, lambda_attenuation=0.25, num_iter=3, dst=None,
+                             solver=SOLVER_WAVE):
     """EF.hpp:413, FGS.cpp:687-691."""
-    return createFastGlobalSmootherFilter(guide, lambda_, sigma_color, lambda_attenuation, num_iter).filter(src, dst)
+    return createFastGlobalSmootherFilter(guide, lambda_, sigma_color, lambda_attenuation, num_iter, solver).filter(src, dst)
 
 
 # ---------------------------------------------------------------------------------------------

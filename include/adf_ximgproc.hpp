@@ -247,7 +247,7 @@ class FastGlobalSmootherFilter {
     int rows_, cols_;
 public:
     FastGlobalSmootherFilter(const Mat& guide, double lambda, double sigma_color, double lambda_attenuation, int num_iter,
-                             int solver = ADF_SOLVER_EXACT)
+                             int solver = ADF_SOLVER_WAVE)
         : rows_(guide.rows), cols_(guide.cols)
     {
         if (guide.empty() || mat_depth(guide) != D8U)                          // FGS.cpp:143-144

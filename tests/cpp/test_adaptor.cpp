@@ -50,6 +50,7 @@ int main()
         make_example(320, 240, cn, 7u + cn, view, dl, dr, roi);                 // szQVGA, T_DF:153
         Ptr<DisparityWLSFilter> wls = createDisparityWLSFilterGeneric(use_conf); // T_DF:137
         wls->setLambda(8000.0); wls->setSigmaColor(1.5);
+        wls->setSolver(ADF_SOLVER_EXACT);                                        // extension; a new filter uses ADF_SOLVER_WAVE
         Mat res;
         wls->filter(dl, view, res, use_conf ? dr : Mat(), roi);                 // T_DF:143
         // the same call on the CPU oracle

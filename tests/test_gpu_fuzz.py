@@ -35,6 +35,7 @@ def test_random_case(adf, oracle, seed):
     p.lambda_ = c["lam"]
     exp, exp_conf = oracle.wls_filter(c["dl"], c["view"], c["dr"] if c["use_conf"] else None, c["roi"], p)
     f = adf.createDisparityWLSFilterGeneric(c["use_conf"])
+    f.setSolver(adf.SOLVER_EXACT)
     f.setLambda(c["lam"]); f.setSigmaColor(c["sigma"]); f.setDepthDiscontinuityRadius(c["radius"])
     f.setLRCthresh(c["thresh"]); f.setFGSParams(c["atten"], c["num_iter"])
     got = f.filter(c["dl"], c["view"], None, c["dr"] if c["use_conf"] else None, c["roi"])

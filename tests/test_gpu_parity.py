@@ -16,6 +16,7 @@ def _oracle_run(oracle, dl, view, dr, roi, **kw):
 
 def _gpu_filter(adf, use_conf, **params):
     f = adf.createDisparityWLSFilterGeneric(use_conf)
+    f.setSolver(adf.SOLVER_EXACT)                      # this file: bit-exactness of the scalar-order solver
     if "lambda" in params: f.setLambda(params["lambda"])
     if "sigma_color" in params: f.setSigmaColor(params["sigma_color"])
     if "disc_radius" in params: f.setDepthDiscontinuityRadius(params["disc_radius"])
@@ -73,6 +74,7 @@ def test_offsets_from_matcher(adf, oracle):
     for m, roi, radius in ((adf.StereoSGBM.create(0, 32, 5), (32, 0, 128, 120), 3),
                            (adf.StereoBM.create(32, 9), (36, 4, 120, 112), 3)):
         f = adf.createDisparityWLSFilter(m)
+        f.setSolver(adf.SOLVER_EXACT)
         assert f.getDepthDiscontinuityRadius() == radius
         f.setSigmaColor(1.5)
         got = f.filter(dl, view, None, dr)            # no ROI given -> offsets (DF.cpp:231-233)
@@ -216,7 +218,7 @@ def test_generic_fgs_api(adf, oracle, dt, cn, gch):
     else: src = rng.integers(0, 255, shape).astype(np.uint8)
     lam, sig = float(rng.uniform(100, 10000)), float(rng.uniform(1.0, 100.0))
     exp = oracle.fgs_filter(guide, src, lam, sig, threads=4)
-    got = adf.fastGlobalSmootherFilter(guide, src, lam, sig)
+    got = adf.fastGlobalSmootherFilter(guide, src, lam, sig, solver=adf.SOLVER_EXACT)
     assert got.dtype == src.dtype and np.array_equal(got, exp)
 
 
@@ -233,7 +235,7 @@ def test_generic_fgs_device_pointers(adf, oracle, dt, cn):
     elif dt == np.int16: src = rng.integers(-32767, 32767, shape).astype(np.int16)
     else: src = rng.integers(0, 255, shape).astype(np.uint8)
     exp = oracle.fgs_filter(guide, src, 500.0, 1.5, threads=4)      # EdgeAwareInterpolator's settings
-    f = adf.createFastGlobalSmootherFilter(guide, 500.0, 1.5)
+    f = adf.createFastGlobalSmootherFilter(guide, 500.0, 1.5, solver=adf.SOLVER_EXACT)
     t = torch.from_numpy(src).cuda()
     got = f.filter(t)
     assert got.is_cuda and got.dtype == t.dtype

@@ -196,6 +196,8 @@ def test_switching_solvers_on_one_handle(adf, oracle):
     view, dl, dr, roi = synthetic.make_artificial_example(300, 200, 3, seed=31)
     exp, _ = oracle.wls_filter(dl, view, dr, roi, oracle.default_params(threads=8))
     f = adf.createDisparityWLSFilterGeneric(True)
+    assert f.getSolver() == adf.SOLVER_WAVE                     # what a new handle uses
+    f.setSolver(adf.SOLVER_EXACT)
     a = f.filter(dl, view, None, dr, roi)                       # exact first (fills planes in T layout)
     assert np.array_equal(a, exp)
     f.setSolver(adf.SOLVER_WAVE)

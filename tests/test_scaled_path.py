@@ -62,6 +62,7 @@ def test_downscaled_disparity_parity(adf, oracle, size, ch, use_conf):
     p = oracle.default_params(sigma_color=1.5, threads=8, use_confidence=int(use_conf))
     exp, exp_conf = oracle.wls_filter_scaled(dl, view, dr if use_conf else None, roi, p)
     f = adf.createDisparityWLSFilterGeneric(use_conf)
+    f.setSolver(adf.SOLVER_EXACT)
     f.setSigmaColor(1.5)
     got = f.filter(dl, view, None, dr if use_conf else None, roi)
     assert got.shape == (h, w)                                   # view-sized output, DF.cpp:252,282
