@@ -72,6 +72,24 @@ __device__ __forceinline__ void launder(float (&v)[M])
 template <bool REFINE>
 __device__ __forceinline__ float rcp_sel(float x) { return REFINE ? rcp_nr(x) : __builtin_amdgcn_rcpf(x); }
 
+// Quotient x / den from a reciprocal r of den.  x * r carries the reciprocal's rounding AND the product's;
+// one residual step (two FMAs) makes the quotient correctly rounded in all but rare cases, i.e. as good as
+// the IEEE division of the scalar order.  Measured against the float64 banded solve on the badly
+// conditioned draws of tests/test_gpu_fuzz.py (mean |error| of the float planes, in LSB of the output):
+// scalar order 0.060; wave solver 0.073 with plain products, 0.059 with the residual step in the boundary
+// sweeps (bit 0; the other two phases do not matter), at +2.3 % of a BASELINE step (the fused first row
+// pass +11 %).  It changes nothing in how often the two float32 evaluations round differently, which is
+// what the parity tests measure, so the build default is 0; -DADF_WAVE_DIVFIX=1 buys the accuracy.
+#ifndef ADF_WAVE_DIVFIX
+#define ADF_WAVE_DIVFIX 0   // bit 0: boundary sweeps, bit 1: interior solve, bit 2: reduced system
+#endif
+template <int WHERE>
+__device__ __forceinline__ float qdiv(float x, float den, float r)
+{
+    const float q = x * r;
+    return (ADF_WAVE_DIVFIX & WHERE) ? __builtin_fmaf(__builtin_fmaf(-den, q, x), r, q) : q;
+}
+
 #ifndef ADF_WAVE_REFINE_BOUNDARY
 #define ADF_WAVE_REFINE_BOUNDARY 1
 #endif
@@ -98,16 +116,18 @@ __device__ __forceinline__ void chunk_boundary(const float (&c)[NC][M], const fl
 #endif
     // left -> right: x_i + D_i x_{i+1} = g_i - p_i xL;   right -> left: x_i + E_i x_{i-1} = h_i - q_i xR
     float D[NC], g0[NC], g1[NC], p[NC];
-    float r[NC], h0[NC], h1[NC], q[NC];
+    float r[NC], dr[NC], h0[NC], h1[NC], q[NC];
 #pragma unroll
     for (int e = 0; e < NC; e++) {
         const float a = a_s[e];
-        const float rl = rcp_sel<NRB>((1.0f - a) - c[e][0]);
-        D[e] = c[e][0] * rl; g0[e] = f0[e][0] * rl; g1[e] = (R > 1) ? f1[e][0] * rl : 0.0f; p[e] = a * rl;
+        const float dl = (1.0f - a) - c[e][0];
+        const float rl = rcp_sel<NRB>(dl);
+        D[e] = qdiv<1>(c[e][0], dl, rl); g0[e] = qdiv<1>(f0[e][0], dl, rl); g1[e] = (R > 1) ? qdiv<1>(f1[e][0], dl, rl) : 0.0f; p[e] = qdiv<1>(a, dl, rl);
         const float ci = c[e][M - 2];
         const float ar = (M - 2 == 0) ? a_s[e] : c[e][(M - 3 > 0) ? M - 3 : 0];
-        r[e] = rcp_sel<NRB>((1.0f - ar) - ci);
-        h0[e] = f0[e][M - 2] * r[e]; h1[e] = (R > 1) ? f1[e][M - 2] * r[e] : 0.0f; q[e] = ci * r[e];
+        dr[e] = (1.0f - ar) - ci;
+        r[e] = rcp_sel<NRB>(dr[e]);
+        h0[e] = qdiv<1>(f0[e][M - 2], dr[e], r[e]); h1[e] = (R > 1) ? qdiv<1>(f1[e][M - 2], dr[e], r[e]) : 0.0f; q[e] = qdiv<1>(ci, dr[e], r[e]);
     }
 #pragma unroll
     for (int t = 1; t <= M - 2; t++) {
@@ -117,11 +137,12 @@ __device__ __forceinline__ void chunk_boundary(const float (&c)[NC][M], const fl
             {
                 const float a = c[e][i - 1];
                 const float b = (1.0f - a) - c[e][i];
-                const float rl = rcp_sel<NRB>(__builtin_fmaf(-a, D[e], b));
-                D[e] = c[e][i] * rl;
-                g0[e] = __builtin_fmaf(-a, g0[e], f0[e][i]) * rl;
-                if (R > 1) g1[e] = __builtin_fmaf(-a, g1[e], f1[e][i]) * rl;
-                p[e] = (-a * p[e]) * rl;
+                const float dl = __builtin_fmaf(-a, D[e], b);
+                const float rl = rcp_sel<NRB>(dl);
+                D[e] = qdiv<1>(c[e][i], dl, rl);
+                g0[e] = qdiv<1>(__builtin_fmaf(-a, g0[e], f0[e][i]), dl, rl);
+                if (R > 1) g1[e] = qdiv<1>(__builtin_fmaf(-a, g1[e], f1[e][i]), dl, rl);
+                p[e] = qdiv<1>(-a * p[e], dl, rl);
                 asm volatile("" : "+v"(p[e])); // p feeds nothing until the end: keep its chain in step
             }
             {
@@ -131,10 +152,11 @@ __device__ __forceinline__ void chunk_boundary(const float (&c)[NC][M], const fl
                 float a = (j == 0) ? a_s[e] : c[e][(j > 0) ? j - 1 : 0];
                 asm volatile("" : "+v"(ci), "+v"(a));
                 const float b = (1.0f - a) - ci;
-                r[e] = rcp_sel<NRB>(__builtin_fmaf(-ci * ci, r[e], b));
-                h0[e] = __builtin_fmaf(-ci, h0[e], f0[e][j]) * r[e];
-                if (R > 1) h1[e] = __builtin_fmaf(-ci, h1[e], f1[e][j]) * r[e];
-                q[e] = (-ci * q[e]) * r[e];
+                dr[e] = __builtin_fmaf(-ci * ci, r[e], b);
+                r[e] = rcp_sel<NRB>(dr[e]);
+                h0[e] = qdiv<1>(__builtin_fmaf(-ci, h0[e], f0[e][j]), dr[e], r[e]);
+                if (R > 1) h1[e] = qdiv<1>(__builtin_fmaf(-ci, h1[e], f1[e][j]), dr[e], r[e]);
+                q[e] = qdiv<1>(-ci * q[e], dr[e], r[e]);
                 asm volatile("" : "+v"(q[e]));
             }
         }
@@ -143,7 +165,7 @@ __device__ __forceinline__ void chunk_boundary(const float (&c)[NC][M], const fl
 #pragma unroll
     for (int e = 0; e < NC; e++) {
         o[e].GE0 = g0[e]; o[e].GE1 = g1[e]; o[e].PE = p[e]; o[e].QE = D[e];
-        o[e].GS0 = h0[e]; o[e].GS1 = h1[e]; o[e].PS = a_s[e] * r[e]; o[e].QS = q[e];
+        o[e].GS0 = h0[e]; o[e].GS1 = h1[e]; o[e].PS = qdiv<1>(a_s[e], dr[e], r[e]); o[e].QS = q[e];
     }
 }
 
@@ -171,10 +193,11 @@ __device__ __forceinline__ void chunk_solve(float (&c)[NC][M], float (&f0)[NC][M
     for (int e = 0; e < NC; e++) {
         const float a = a_s[e];
         corig[e] = c[e][0];
-        const float r = rcp_sel<NRS>((1.0f - a) - corig[e]);
-        D[e] = corig[e] * r;
-        g0[e] = __builtin_fmaf(-a, xL0[e], f0[e][0]) * r;
-        g1[e] = (R > 1) ? __builtin_fmaf(-a, xL1[e], f1[e][0]) * r : 0.0f;
+        const float dn = (1.0f - a) - corig[e];
+        const float r = rcp_sel<NRS>(dn);
+        D[e] = qdiv<2>(corig[e], dn, r);
+        g0[e] = qdiv<2>(__builtin_fmaf(-a, xL0[e], f0[e][0]), dn, r);
+        g1[e] = (R > 1) ? qdiv<2>(__builtin_fmaf(-a, xL1[e], f1[e][0]), dn, r) : 0.0f;
         c[e][0] = D[e]; f0[e][0] = g0[e]; if (R > 1) f1[e][0] = g1[e];
     }
 #pragma unroll
@@ -184,10 +207,11 @@ __device__ __forceinline__ void chunk_solve(float (&c)[NC][M], float (&f0)[NC][M
             const float a = corig[e];
             corig[e] = c[e][i];
             const float b = (1.0f - a) - corig[e];
-            const float r = rcp_sel<NRS>(__builtin_fmaf(-a, D[e], b));
-            D[e] = corig[e] * r;
-            g0[e] = __builtin_fmaf(-a, g0[e], f0[e][i]) * r;
-            if (R > 1) g1[e] = __builtin_fmaf(-a, g1[e], f1[e][i]) * r;
+            const float dn = __builtin_fmaf(-a, D[e], b);
+            const float r = rcp_sel<NRS>(dn);
+            D[e] = qdiv<2>(corig[e], dn, r);
+            g0[e] = qdiv<2>(__builtin_fmaf(-a, g0[e], f0[e][i]), dn, r);
+            if (R > 1) g1[e] = qdiv<2>(__builtin_fmaf(-a, g1[e], f1[e][i]), dn, r);
             c[e][i] = D[e]; f0[e][i] = g0[e]; if (R > 1) f1[e][i] = g1[e];
         }
         ADF_STEP_FENCE();
@@ -229,6 +253,13 @@ __device__ __forceinline__ v2f vrcp_sel(v2f x)
     return REFINE ? vfma(vfma(-x, r, vsplat(1.0f)), r, r) : r;
 }
 
+template <int WHERE>
+__device__ __forceinline__ v2f vqdiv(v2f x, v2f den, v2f r)
+{
+    const v2f q = x * r;
+    return (ADF_WAVE_DIVFIX & WHERE) ? vfma(vfma(-den, q, x), r, q) : q;
+}
+
 template <int R>
 struct Boundary2 { v2f GS0, GS1, PS, QS, GE0, GE1, PE, QE; };
 
@@ -238,14 +269,16 @@ __device__ __forceinline__ void chunk_boundary2(const v2f (&c)[M], const v2f (&f
     constexpr bool NRB = ADF_WAVE_REFINE_BOUNDARY != 0;
     const v2f one = vsplat(1.0f), zero = vsplat(0.0f);
     // left -> right: x_i + D_i x_{i+1} = g_i - p_i xL;   right -> left: x_i + E_i x_{i-1} = h_i - q_i xR
-    v2f D, g0, g1, p, r, h0, h1, q;
+    v2f D, g0, g1, p, r, dr, h0, h1, q;
     {
-        const v2f rl = vrcp_sel<NRB>((one - a_s) - c[0]);
-        D = c[0] * rl; g0 = f0[0] * rl; g1 = (R > 1) ? f1[0] * rl : zero; p = a_s * rl;
+        const v2f dl = (one - a_s) - c[0];
+        const v2f rl = vrcp_sel<NRB>(dl);
+        D = vqdiv<1>(c[0], dl, rl); g0 = vqdiv<1>(f0[0], dl, rl); g1 = (R > 1) ? vqdiv<1>(f1[0], dl, rl) : zero; p = vqdiv<1>(a_s, dl, rl);
         const v2f ci = c[M - 2];
         const v2f ar = (M - 2 == 0) ? a_s : c[(M - 3 > 0) ? M - 3 : 0];
-        r = vrcp_sel<NRB>((one - ar) - ci);
-        h0 = f0[M - 2] * r; h1 = (R > 1) ? f1[M - 2] * r : zero; q = ci * r;
+        dr = (one - ar) - ci;
+        r = vrcp_sel<NRB>(dr);
+        h0 = vqdiv<1>(f0[M - 2], dr, r); h1 = (R > 1) ? vqdiv<1>(f1[M - 2], dr, r) : zero; q = vqdiv<1>(ci, dr, r);
     }
 #pragma unroll
     for (int t = 1; t <= M - 2; t++) {
@@ -253,11 +286,12 @@ __device__ __forceinline__ void chunk_boundary2(const v2f (&c)[M], const v2f (&f
         {
             const v2f a = c[i - 1];
             const v2f b = (one - a) - c[i];
-            const v2f rl = vrcp_sel<NRB>(vfma(-a, D, b));
-            D = c[i] * rl;
-            g0 = vfma(-a, g0, f0[i]) * rl;
-            if (R > 1) g1 = vfma(-a, g1, f1[i]) * rl;
-            p = (-a * p) * rl;
+            const v2f dl = vfma(-a, D, b);
+            const v2f rl = vrcp_sel<NRB>(dl);
+            D = vqdiv<1>(c[i], dl, rl);
+            g0 = vqdiv<1>(vfma(-a, g0, f0[i]), dl, rl);
+            if (R > 1) g1 = vqdiv<1>(vfma(-a, g1, f1[i]), dl, rl);
+            p = vqdiv<1>(-a * p, dl, rl);
             // pin every chain to its step: pure arithmetic is not ordered against the fence below by
             // instruction selection, and a chain that drifts out of the loop drags one reciprocal per
             // step along with it (the right-hand-side chains feed nothing until the end)
@@ -271,17 +305,18 @@ __device__ __forceinline__ void chunk_boundary2(const v2f (&c)[M], const v2f (&f
             v2f a = (j == 0) ? a_s : c[(j > 0) ? j - 1 : 0];
             asm volatile("" : "+v"(ci), "+v"(a));
             const v2f b = (one - a) - ci;
-            r = vrcp_sel<NRB>(vfma(-ci * ci, r, b));
-            h0 = vfma(-ci, h0, f0[j]) * r;
-            if (R > 1) h1 = vfma(-ci, h1, f1[j]) * r;
-            q = (-ci * q) * r;
+            dr = vfma(-ci * ci, r, b);
+            r = vrcp_sel<NRB>(dr);
+            h0 = vqdiv<1>(vfma(-ci, h0, f0[j]), dr, r);
+            if (R > 1) h1 = vqdiv<1>(vfma(-ci, h1, f1[j]), dr, r);
+            q = vqdiv<1>(-ci * q, dr, r);
             if (R > 1) asm volatile("" : "+v"(h0), "+v"(h1), "+v"(q));
             else asm volatile("" : "+v"(h0), "+v"(q));
         }
         ADF_STEP_FENCE();
     }
     o.GE0 = g0; o.GE1 = g1; o.PE = p; o.QE = D;
-    o.GS0 = h0; o.GS1 = h1; o.PS = a_s * r; o.QS = q;
+    o.GS0 = h0; o.GS1 = h1; o.PS = vqdiv<1>(a_s, dr, r); o.QS = q;
 }
 
 template <int M, int R>
@@ -293,10 +328,11 @@ __device__ __forceinline__ void chunk_solve2(v2f (&c)[M], v2f (&f0)[M], v2f (&f1
     for (int i = 0; i < M; i++) asm volatile("" : "+v"(c[i]));
     v2f corig = c[0], D, g0, g1;
     {
-        const v2f r = vrcp_sel<NRS>((one - a_s) - corig);
-        D = corig * r;
-        g0 = vfma(-a_s, xL0, f0[0]) * r;
-        g1 = (R > 1) ? vfma(-a_s, xL1, f1[0]) * r : zero;
+        const v2f dn = (one - a_s) - corig;
+        const v2f r = vrcp_sel<NRS>(dn);
+        D = vqdiv<2>(corig, dn, r);
+        g0 = vqdiv<2>(vfma(-a_s, xL0, f0[0]), dn, r);
+        g1 = (R > 1) ? vqdiv<2>(vfma(-a_s, xL1, f1[0]), dn, r) : zero;
         c[0] = D; f0[0] = g0; if (R > 1) f1[0] = g1;
     }
 #pragma unroll
@@ -304,10 +340,11 @@ __device__ __forceinline__ void chunk_solve2(v2f (&c)[M], v2f (&f0)[M], v2f (&f1
         const v2f a = corig;
         corig = c[i];
         const v2f b = (one - a) - corig;
-        const v2f r = vrcp_sel<NRS>(vfma(-a, D, b));
-        D = corig * r;
-        g0 = vfma(-a, g0, f0[i]) * r;
-        if (R > 1) g1 = vfma(-a, g1, f1[i]) * r;
+        const v2f dn = vfma(-a, D, b);
+        const v2f r = vrcp_sel<NRS>(dn);
+        D = vqdiv<2>(corig, dn, r);
+        g0 = vqdiv<2>(vfma(-a, g0, f0[i]), dn, r);
+        if (R > 1) g1 = vqdiv<2>(vfma(-a, g1, f1[i]), dn, r);
         c[i] = D; f0[i] = g0; if (R > 1) f1[i] = g1;
         if (R > 1) asm volatile("" : "+v"(D), "+v"(g0), "+v"(g1));
         else asm volatile("" : "+v"(D), "+v"(g0));
@@ -367,7 +404,7 @@ __device__ __forceinline__ void pcr64(int lane, float al, float be, float ga, fl
         float fp1 = (R > 1) ? __shfl_down(p1, d) : 0.0f;
         if (lane < d) { am = 0.0f; bm = 1.0f; gm = 0.0f; fm0 = 0.0f; fm1 = 0.0f; }
         if (lane + d > 63) { ap = 0.0f; bp = 1.0f; gp = 0.0f; fp0 = 0.0f; fp1 = 0.0f; }
-        const float k1 = al * rcp_nr(bm), k2 = ga * rcp_nr(bp);
+        const float k1 = qdiv<4>(al, bm, rcp_nr(bm)), k2 = qdiv<4>(ga, bp, rcp_nr(bp));
         be = __builtin_fmaf(-ap, k2, __builtin_fmaf(-gm, k1, be));
         p0 = __builtin_fmaf(-fp0, k2, __builtin_fmaf(-fm0, k1, p0));
         if (R > 1) p1 = __builtin_fmaf(-fp1, k2, __builtin_fmaf(-fm1, k1, p1));
@@ -375,8 +412,8 @@ __device__ __forceinline__ void pcr64(int lane, float al, float be, float ga, fl
         ga = -gp * k2;
     }
     const float rb = rcp_nr(be);
-    x0 = p0 * rb;
-    x1 = (R > 1) ? p1 * rb : 0.0f;
+    x0 = qdiv<4>(p0, be, rb);
+    x1 = (R > 1) ? qdiv<4>(p1, be, rb) : 0.0f;
 }
 
 
