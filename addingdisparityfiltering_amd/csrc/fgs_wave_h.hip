@@ -52,23 +52,25 @@ __global__ void __launch_bounds__(64, (M > ADF_H_TWO_WAVE_MAX && R > 1) ? 1 : 2)
                                                  (ptrdiff_t)(a.dl_y0 + blockIdx.x) * a.dl_stride + (ptrdiff_t)a.dl_x0 * 2);
         }
         const int nfused = a.len >> 2;
+        short4 draw[FUSED ? M / 4 : 1];                          // fused: the row of the left disparity map
         // (an explicit branch per load: "cond ? *p : zero" would make the compiler select between
         // addresses and park the zero in scratch memory)
 #pragma unroll
         for (int k = 0; k < M / 4; k++) {
             const int idx = 64 * k + lane;
             tC[k] = make_float4(0.f, 0.f, 0.f, 0.f); t0[k] = tC[k]; t1[k] = tC[k];
+            if (FUSED) draw[k] = make_short4(0, 0, 0, 0);
             if (FUSED) {
                 typedef float v4f __attribute__((ext_vector_type(4)));
                 typedef short v4s __attribute__((ext_vector_type(4)));
                 if (idx < nvec) { const v4f q = __builtin_nontemporal_load(reinterpret_cast<const v4f*>(sC) + idx); tC[k] = make_float4(q.x, q.y, q.z, q.w); }
+                // loads only: the products conf*float(dL) wait for the second loop, or every iteration would
+                // wait for its own loads before the next one's are issued (14 memory latencies per row)
                 if (idx < nfused) {
                     const v4f cq = __builtin_nontemporal_load(reinterpret_cast<const v4f*>(sF) + idx);
                     const v4s dq = __builtin_nontemporal_load(reinterpret_cast<const v4s*>(sD) + idx);
-                    const float4 cf = make_float4(cq.x, cq.y, cq.z, cq.w);
-                    const short4 dd = make_short4(dq.x, dq.y, dq.z, dq.w);
-                    t1[k] = cf;
-                    t0[k] = make_float4(cf.x * (float)dd.x, cf.y * (float)dd.y, cf.z * (float)dd.z, cf.w * (float)dd.w);
+                    t1[k] = make_float4(cq.x, cq.y, cq.z, cq.w);
+                    draw[k] = make_short4(dq.x, dq.y, dq.z, dq.w);
                 }
             } else {
                 // non-temporal: every byte of a row pass is used exactly once (measured -5 % on the pass)
@@ -77,6 +79,11 @@ __global__ void __launch_bounds__(64, (M > ADF_H_TWO_WAVE_MAX && R > 1) ? 1 : 2)
                 if (idx < nvecU) { const v4f q = __builtin_nontemporal_load(reinterpret_cast<const v4f*>(s0) + idx); t0[k] = make_float4(q.x, q.y, q.z, q.w); }
                 if (PAIR && idx + 64 * MQ < nvecU) { const v4f q = __builtin_nontemporal_load(reinterpret_cast<const v4f*>(s1) + idx); t1[k] = make_float4(q.x, q.y, q.z, q.w); }
             }
+        }
+        if (FUSED) {                                             // U1 = conf, U0 = conf * float(dL)  (DF.cpp:288-290)
+#pragma unroll
+            for (int k = 0; k < M / 4; k++)
+                t0[k] = make_float4(t1[k].x * (float)draw[k].x, t1[k].y * (float)draw[k].y, t1[k].z * (float)draw[k].z, t1[k].w * (float)draw[k].w);
         }
     }
     // columns [len, pitch) of every plane are zero by construction (the host zeroes the workspace
