@@ -161,9 +161,23 @@ __global__ void __launch_bounds__(NT) weights_stream_kernel(WeightArgs a)
         const int nw = (m + need + 3) >> 2;
         return tid < nw ? reinterpret_cast<const unsigned*>(rp - m)[tid] : 0u;
     };
+    // Head of the table from LDS.  The rare large index (a strong colour edge) is fetched with a SCALAR
+    // load, one needy lane at a time: a vector load here -- even one that almost never executes -- makes the
+    // compiler wait for vmcnt(0) before every store of the row loop, and on this target stores count in
+    // vmcnt too, so every row's stores would wait for the previous row's to be acknowledged.
     auto lookup = [&](int idx) -> float {
         float w = lut_head[min(idx, LUT_HEAD - 1)];
-        if (idx >= LUT_HEAD) w = a.lut[idx];                   // rare: strong colour edge
+        bool need = idx >= LUT_HEAD;
+        unsigned long long m = __ballot(need);
+        while (m) {                                            // wave-uniform
+            const int first = __ffsll((long long)m) - 1;
+            const int sidx = __builtin_amdgcn_readfirstlane(__shfl(idx, first));
+            // constant address space + uniform index = s_load_dword (lgkmcnt, not vmcnt); the table is
+            // written once by the host, long before this launch
+            const float ws = reinterpret_cast<const __attribute__((address_space(4))) float*>(reinterpret_cast<uintptr_t>(a.lut))[sidx];
+            if ((int)(threadIdx.x & 63) == first) { w = ws; need = false; }
+            m = __ballot(need);
+        }
         return w;
     };
 
