@@ -274,7 +274,7 @@ __global__ void __launch_bounds__(NT) conf_left_kernel(ConfLeftArgs a)
     for (int s = 0; s < U; s++) nxt[s] = (s < nrows) ? load(s) : 0;
     for (int n0 = 0; n0 < nrows; n0 += U) {
 #pragma unroll
-        for (int s = 0; s < U; s++) cur[s] = nxt[s];
+        for (int s = 0; s < U; s++) { cur[s] = nxt[s]; asm volatile("" : "+v"(cur[s])); }
 #pragma unroll
         for (int s = 0; s < U; s++) {                             // gathers for centre rows n0 .. n0+U-1
             const int n = n0 + s;
@@ -288,6 +288,13 @@ __global__ void __launch_bounds__(NT) conf_left_kernel(ConfLeftArgs a)
                 }
             }
         }
+        // One wait per group, placed by hand: the gathers have to be back before the first window of the
+        // group completes, and behind the block-uniform branches of the row loop the compiler can only wait
+        // for vmcnt(0) at every use -- which, stores counting in vmcnt here, also waits for the previous
+        // row's store to be acknowledged.  After this point the group's inputs are plain registers; the next
+        // group's rows are requested only now, so they and the stores stay in flight across the row loop.
+#pragma unroll
+        for (int s = 0; s < U; s++) asm volatile("" : "+v"(gd[s]), "+v"(gc[s]));
 #pragma unroll
         for (int s = 0; s < U; s++) nxt[s] = (n0 + U + s < nrows) ? load(n0 + U + s) : 0;
 #pragma unroll
