@@ -191,7 +191,9 @@ __global__ void __launch_bounds__(NT) discontinuity_col_kernel(DiscArgs a)
     for (int n0 = 0; n0 < nrows; n0 += U) {
         int cur[U];
 #pragma unroll
-        for (int s = 0; s < U; s++) { cur[s] = nxt[s]; nxt[s] = (n0 + U + s < nrows) ? load(n0 + U + s) : 0; }
+        for (int s = 0; s < U; s++) { cur[s] = nxt[s]; asm volatile("" : "+v"(cur[s])); }   // the group's one wait happens here
+#pragma unroll
+        for (int s = 0; s < U; s++) nxt[s] = (n0 + U + s < nrows) ? load(n0 + U + s) : 0;          // in flight across the rows below
 #pragma unroll
         for (int s = 0; s < U; s++) {
             const int n = n0 + s;

@@ -189,7 +189,9 @@ __global__ void __launch_bounds__(NT) weights_stream_kernel(WeightArgs a)
     for (int s = 0; s < WS_U; s++) nxt[s] = (s < nrows) ? load(s) : 0u;
     for (int n0 = 0; n0 < nrows; n0 += WS_U) {
 #pragma unroll
-        for (int s = 0; s < WS_U; s++) { cur[s] = nxt[s]; nxt[s] = (n0 + WS_U + s < nrows) ? load(n0 + WS_U + s) : 0u; }
+        for (int s = 0; s < WS_U; s++) { cur[s] = nxt[s]; asm volatile("" : "+v"(cur[s])); }   // the group's one wait happens here
+#pragma unroll
+        for (int s = 0; s < WS_U; s++) nxt[s] = (n0 + WS_U + s < nrows) ? load(n0 + WS_U + s) : 0u;  // in flight across the rows below
 #pragma unroll
         for (int s = 0; s < WS_U; s++) {
             const int n = n0 + s;
