@@ -394,25 +394,45 @@ __global__ void __launch_bounds__(NT) lrc_prologue_kernel(LrcArgs a)
     const int j = x0 + tx;
     const int right_end = a.rrx + g.rw;
 
+    // Three phases over the thread's TY/4 pixels -- own values, the gathers they address, then arithmetic and
+    // stores -- so that no loaded value is first used inside the storing loop (stores count in vmcnt on this
+    // target: a wait for a load there would also wait for every store issued before it).
+    constexpr int NK = TY / 4;
+    int dv[NK], drv[NK]; float cv[NK], bv[NK]; bool roi_k[NK], hit[NK];
 #pragma unroll
-    for (int kk = 0; kk < TY / 4; kk++) {
+    for (int kk = 0; kk < NK; kk++) {
+        const int i = y0 + ty + 4 * kk;
+        roi_k[kk] = i < g.H && j < g.W && j >= g.rx && j < g.rx + g.rw && i >= g.ry && i < g.ry + g.rh;
+        dv[kk] = 0; cv[kk] = 0.0f;
+        if (roi_k[kk]) {
+            dv[kk] = reinterpret_cast<const int16_t*>(pL + (ptrdiff_t)i * a.sL)[j];
+            cv[kk] = cL[(size_t)i * g.W + j];
+        }
+    }
+#pragma unroll
+    for (int kk = 0; kk < NK; kk++) {
+        const int i = y0 + ty + 4 * kk;
+        const int ridx = j - (dv[kk] >> 4);                             // DF.cpp:331
+        hit[kk] = roi_k[kk] && ridx >= a.rrx && ridx < right_end;
+        drv[kk] = 0; bv[kk] = 0.0f;
+        if (hit[kk]) {
+            drv[kk] = reinterpret_cast<const int16_t*>(pR + (ptrdiff_t)i * a.sR)[ridx];
+            bv[kk] = cR[(size_t)i * g.W + ridx];
+        }
+    }
+#pragma unroll
+    for (int kk = 0; kk < NK; kk++) asm volatile("" : "+v"(drv[kk]), "+v"(bv[kk]));   // the one wait for the gathers
+#pragma unroll
+    for (int kk = 0; kk < NK; kk++) {
         const int i = y0 + ty + 4 * kk;
         const bool in_frame = i < g.H && j < g.W;
-        const bool in_roi = in_frame && j >= g.rx && j < g.rx + g.rw && i >= g.ry && i < g.ry + g.rh;
-        float c = 0.0f, u0 = 0.0f;
+        const bool in_roi = roi_k[kk];
+        const int d = dv[kk];
+        float c = cv[kk], u0 = 0.0f;
         if (in_roi) {
-            const int16_t* rl = reinterpret_cast<const int16_t*>(pL + (ptrdiff_t)i * a.sL);
-            const int d = rl[j];
-            c = cL[(size_t)i * g.W + j];
-            const int ridx = j - (d >> 4);                              // DF.cpp:331
-            if (ridx >= a.rrx && ridx < right_end) {
-                const int16_t* rr = reinterpret_cast<const int16_t*>(pR + (ptrdiff_t)i * a.sR);
-                const int dr = rr[ridx];
-                if (abs(d + dr) < a.thresh) {                           // DF.cpp:334
-                    const float b = cR[(size_t)i * g.W + ridx];
-                    c = b < c ? b : c;                                  // std::min, DF.cpp:335
-                } else
-                    c = 0.0f;                                           // DF.cpp:337
+            if (hit[kk]) {
+                if (abs(d + drv[kk]) < a.thresh) c = bv[kk] < c ? bv[kk] : c;   // DF.cpp:334-335 (std::min)
+                else c = 0.0f;                                                  // DF.cpp:337
             }
             c = 255.0f * c;                                             // DF.cpp:209
             u0 = c * (float)d;                                          // DF.cpp:289-290
@@ -464,8 +484,11 @@ __global__ void __launch_bounds__(NT) plain_prologue_kernel(PlainPrologueArgs a)
     const bool two = a.conf != nullptr || a.pair2;      // two right-hand sides
     float* U1 = two ? (pair ? U0 + ADF_STRIP : a.U1 + pz * g.plane) : nullptr;
     const int j = x0 + tx;
+    // loads of all TY/4 pixels first, stores afterwards (see lrc_prologue_kernel)
+    constexpr int NK = TY / 4;
+    float v0[NK], v1[NK];
 #pragma unroll
-    for (int kk = 0; kk < TY / 4; kk++) {
+    for (int kk = 0; kk < NK; kk++) {
         const int i = y0 + ty + 4 * kk;
         const bool ok = i < g.rh && j < g.rw;
         float u0 = 0.0f, u1 = 0.0f;
@@ -486,14 +509,22 @@ __global__ void __launch_bounds__(NT) plain_prologue_kernel(PlainPrologueArgs a)
                 u0 = u1 * u0;
             }
         }
+        v0[kk] = u0; v1[kk] = u1;
+    }
+#pragma unroll
+    for (int kk = 0; kk < NK; kk++) asm volatile("" : "+v"(v0[kk]), "+v"(v1[kk]));   // the one wait
+#pragma unroll
+    for (int kk = 0; kk < NK; kk++) {
+        const int i = y0 + ty + 4 * kk;
+        const bool ok = i < g.rh && j < g.rw;
         if (a.orient != ORIENT_T) {
             if (ok) {
                 const size_t o = pair ? pair_index(i, j, g.pw) : (size_t)i * g.pw + j;
-                U0[o] = u0; if (two) U1[o] = u1;
+                U0[o] = v0[kk]; if (two) U1[o] = v1[kk];
             }
         } else {
-            t0[tx * (TY + 1) + ty + 4 * kk] = u0;
-            t1[tx * (TY + 1) + ty + 4 * kk] = u1;
+            t0[tx * (TY + 1) + ty + 4 * kk] = v0[kk];
+            t1[tx * (TY + 1) + ty + 4 * kk] = v1[kk];
         }
     }
     if (a.orient == ORIENT_T) {
