@@ -50,7 +50,7 @@ __global__ void __launch_bounds__(256) resize_linear_kernel(ResizeArgs a)
         return v0 * a0[c] + v1 * a1[c];
     };
     int cy[2] = {-1, -1};
-    float ch0[RC], ch1[RC];
+    float ch0[RC], ch1[RC], res[RR][RC];
 #pragma unroll
     for (int c = 0; c < RC; c++) { ch0[c] = 0.0f; ch1[c] = 0.0f; }
 #pragma unroll
@@ -83,6 +83,18 @@ __global__ void __launch_bounds__(256) resize_linear_kernel(ResizeArgs a)
             const float r1 = (y1 == cy[0]) ? ch0[c] : ch1[c];
             v[c] = r0 * b0 + r1 * b1;
         }
+#pragma unroll
+        for (int c = 0; c < RC; c++) res[k][c] = v[c];
+    }
+    // stores after all loads (stores count in vmcnt on this target: a row's loads would otherwise wait for the
+    // previous row's stores)
+#pragma unroll
+    for (int k = 0; k < RR; k++) {
+        const int dy = dy0 + k;
+        if (dy >= a.dh) break;
+        float v[RC];
+#pragma unroll
+        for (int c = 0; c < RC; c++) v[c] = res[k][c];
         char* drow = dbase + (ptrdiff_t)dy * a.dstride;
         const bool full = dx0 + RC <= a.dw;
         if (IS16) {
