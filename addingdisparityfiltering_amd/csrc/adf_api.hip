@@ -64,7 +64,7 @@ static Geom make_geom(int W, int H, int rx, int ry, int rw, int rh)
     g.W = W; g.H = H; g.rx = rx; g.ry = ry; g.rw = rw; g.rh = rh;
     g.pw = round_up(rw, 64);
     g.ph = round_up(rh, 64);
-    size_t a = (size_t)rh * g.pw, b = (size_t)rw * g.ph;
+    size_t a = (size_t)((rh + 1) & ~1) * g.pw, b = (size_t)rw * g.ph;   // (the wave solver's pair plane holds rows in pairs)
     g.plane = ((a > b ? a : b) + 63) / 64 * 64;
     g.frame = (size_t)W * H;
     return g;

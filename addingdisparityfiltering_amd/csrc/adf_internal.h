@@ -25,8 +25,10 @@ struct Geom {
 
 // Destination layout of a plane-writing kernel.
 //   ORIENT_PAIR   (wave solver, two right-hand sides) ONE plane of 2*plane floats per image holding
-//                 both: row-major rows of 2*pw floats, [U0 x16 | U1 x16] per 16-column strip, so that a
-//                 strip row of the column pass is one 128-byte line; the U1 pointer is unused
+//                 both, tiled [row pair][16-column strip][row parity][U0 x16 | U1 x16]: a strip row of the
+//                 column pass is one 128-byte line and two consecutive rows of a strip are 256 contiguous
+//                 bytes, while an image row is still 128-byte pieces at a fixed 256-byte stride for the row
+//                 pass; the U1 pointer is unused
 //   ORIENT_STRIP  (wave solver, Cvert) strip-major [pw/16][rh][16]
 enum Orient { ORIENT_N = 0, ORIENT_T = 1, ORIENT_PAIR = 2, ORIENT_STRIP = 3 };
 #define ADF_STRIP 16
@@ -166,7 +168,7 @@ int max_disc_radius();
 // float index of U0(i, j) inside an ORIENT_PAIR plane of pitch pw (U1 is ADF_STRIP floats further)
 __device__ __forceinline__ size_t pair_index(int i, int j, int pw)
 {
-    return (size_t)i * (size_t)(2 * pw) + (size_t)(((j >> 4) << 5) + (j & 15));
+    return (size_t)(i >> 1) * (size_t)(4 * pw) + (size_t)(((j >> 4) << 6) + ((i & 1) << 5) + (j & 15));
 }
 // float index of C(i, j) inside an ORIENT_STRIP plane of rh rows
 __device__ __forceinline__ size_t strip_index(int i, int j, int rh)

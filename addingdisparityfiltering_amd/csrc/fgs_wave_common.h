@@ -30,10 +30,12 @@
 //   Cvert           strip-major [pw/16][rh][16]: the weights of a vertical strip are one contiguous stream
 //   one right-hand side (R == 1)    row-major [rh][pw]; a strip row is then a 64-byte half line (the
 //                   other half is served from L2/MALL to the neighbouring strip)
-//   two right-hand sides (R == 2)   ONE pair plane [rh][pw/16][U0 x16 | U1 x16] of 2*plane floats per
-//                   image: the row pass still streams whole contiguous rows (it de-interleaves in its
-//                   LDS staging buffer), and a strip row of the column pass is one full 128-byte line
-//                   holding both right-hand sides.  U1 pointers are ignored for R == 2.
+//   two right-hand sides (R == 2)   ONE pair plane [rh/2][pw/16][row parity][U0 x16 | U1 x16] of 2*plane
+//                   floats per image: a strip row of the column pass is one full 128-byte line holding
+//                   both right-hand sides and two consecutive rows are 256 contiguous bytes; the row pass
+//                   reads an image row as 128-byte pieces at a 256-byte stride (the other row of the pair
+//                   fills the gaps) and de-interleaves in its LDS staging buffer.  Measured against plain
+//                   row-major pair rows: column pass -6 %, row pass +3.5 %.  U1 pointers are ignored.
 #pragma once
 #include "adf_internal.h"
 

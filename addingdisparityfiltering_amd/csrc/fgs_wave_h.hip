@@ -29,7 +29,9 @@ __global__ void __launch_bounds__(64, (M > ADF_H_TWO_WAVE_MAX && R > 1) ? 1 : 2)
     // R == 2: the two right-hand sides live in one pair plane, interleaved per 16 columns
     // ([U0 x16 | U1 x16] per strip, see fgs_wave_common.h): a row is 2*pitch contiguous floats
     constexpr bool PAIR = R > 1;
-    const size_t offU = PAIR ? 2 * off : off;
+    // (rows come in pairs: float4 #q of pair row r lives at (r/2)*(2*nvecU) + (q/8)*16 + (r%2)*8 + q%8)
+    const size_t offU = PAIR ? (size_t)blockIdx.y * 2 * a.plane + (size_t)(blockIdx.x >> 1) * (size_t)(4 * a.pitch) + (size_t)(blockIdx.x & 1) * 32 : off;
+#define ADF_PIDX(q) (PAIR ? ((((q) >> 3) << 4) + ((q) & 7)) : (q))
     const int nvecU = PAIR ? 2 * nvec : nvec;
     constexpr int MQ = M / 4;
     float c[1][M], f0[1][M], f1[1][M];
@@ -42,7 +44,6 @@ __global__ void __launch_bounds__(64, (M > ADF_H_TWO_WAVE_MAX && R > 1) ? 1 : 2)
         const float4* sC = reinterpret_cast<const float4*>(a.C + off);
         // PAIR: t0 / t1 hold the first / second half of the interleaved row instead of U0 / U1
         const float4* s0 = reinterpret_cast<const float4*>(a.U0 + offU);
-        const float4* s1 = PAIR ? s0 + 64 * MQ : nullptr;
         // fused inputs (the launcher guarantees 16 / 8 byte alignment and len % 4 == 0)
         const float4* sF = nullptr; const short4* sD = nullptr;
         if (FUSED) {
@@ -76,8 +77,8 @@ __global__ void __launch_bounds__(64, (M > ADF_H_TWO_WAVE_MAX && R > 1) ? 1 : 2)
                 // non-temporal: every byte of a row pass is used exactly once (measured -5 % on the pass)
                 typedef float v4f __attribute__((ext_vector_type(4)));
                 if (idx < nvec) { const v4f q = __builtin_nontemporal_load(reinterpret_cast<const v4f*>(sC) + idx); tC[k] = make_float4(q.x, q.y, q.z, q.w); }
-                if (idx < nvecU) { const v4f q = __builtin_nontemporal_load(reinterpret_cast<const v4f*>(s0) + idx); t0[k] = make_float4(q.x, q.y, q.z, q.w); }
-                if (PAIR && idx + 64 * MQ < nvecU) { const v4f q = __builtin_nontemporal_load(reinterpret_cast<const v4f*>(s1) + idx); t1[k] = make_float4(q.x, q.y, q.z, q.w); }
+                if (idx < nvecU) { const v4f q = __builtin_nontemporal_load(reinterpret_cast<const v4f*>(s0) + ADF_PIDX(idx)); t0[k] = make_float4(q.x, q.y, q.z, q.w); }
+                if (PAIR && idx + 64 * MQ < nvecU) { const v4f q = __builtin_nontemporal_load(reinterpret_cast<const v4f*>(s0) + ADF_PIDX(idx + 64 * MQ)); t1[k] = make_float4(q.x, q.y, q.z, q.w); }
             }
         }
         if (FUSED) {                                             // U1 = conf, U0 = conf * float(dL)  (DF.cpp:288-290)
@@ -183,7 +184,7 @@ __global__ void __launch_bounds__(64, (M > ADF_H_TWO_WAVE_MAX && R > 1) ? 1 : 2)
 #pragma unroll
             for (int k = 0; k < MQ; k++) {
                 const int idx = 64 * (k + half * MQ) + lane_s;
-                if (idx < nvecU) { const float4 q = stage[64 * k + lane_s]; const v4f o = {q.x, q.y, q.z, q.w}; __builtin_nontemporal_store(o, d4 + idx); }
+                if (idx < nvecU) { const float4 q = stage[64 * k + lane_s]; const v4f o = {q.x, q.y, q.z, q.w}; __builtin_nontemporal_store(o, d4 + ADF_PIDX(idx)); }
             }
             __syncthreads();
         }

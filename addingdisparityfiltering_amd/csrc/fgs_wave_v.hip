@@ -75,14 +75,18 @@ __global__ void __launch_bounds__(VT) wave_vpass_kernel(WavePassArgs a)
     // rows.  Keeping a 64-bit address per row alive from the loads to the stores would cost more
     // registers than the strip itself.
     //   C (Cvert)  strip-major [strip][row][16]: the strip's weights are one contiguous stream
-    //   R == 2     pair plane [row][strip][U0 x16 | U1 x16]: a strip row is one full 128-byte line
+    //   R == 2     pair plane [row pair][strip][row parity][U0 x16 | U1 x16]: a strip row is one full 128-byte
+    //              line, two consecutive rows 256 contiguous bytes
     //   R == 1     plain row-major plane: a strip row is a 64-byte half line
     // (see fgs_wave_common.h; measured -17 % on the pass against three row-major planes)
     const char* bC = reinterpret_cast<const char*>(a.C + pb);
     char* b0 = reinterpret_cast<char*>(a.U0 + (R > 1 ? 2 * pb : pb));
     char* b1 = (R > 1) ? b0 + 4 * VC : nullptr;
     const unsigned pitch_b = (unsigned)a.pitch * (R > 1 ? 8u : 4u);
-    const unsigned voff0 = (R > 1) ? ((unsigned)r0 * (unsigned)a.pitch * 2u + (unsigned)strip * (2u * VC) + 2u * xp) * 4u
+    // pair plane: [row pair][strip][row parity][32 floats]; r0 is even (every chunk length is)
+    static_assert(M % 2 == 0, "chunks must start on an even row");
+#define ADF_VSTEP(i) ((R > 1) ? (((i) & 1) ? (unsigned)a.pitch * 16u - 128u : 128u) : pitch_b)
+    const unsigned voff0 = (R > 1) ? ((unsigned)(r0 >> 1) * (unsigned)a.pitch * 4u + (unsigned)strip * (4u * VC) + 2u * xp) * 4u
                                    : ((unsigned)r0 * (unsigned)a.pitch + (unsigned)col) * 4u;
     const unsigned pitch_c = 4u * VC;
     const unsigned coff0 = (((unsigned)strip * (unsigned)h + (unsigned)r0) * VC + 2u * xp) * 4u;
@@ -91,7 +95,7 @@ __global__ void __launch_bounds__(VT) wave_vpass_kernel(WavePassArgs a)
     // two-column templates in fgs_wave_common.h)
     v2f c[M], f0[M], f1[M];
     // row 0 of the column: always inside the planes
-    const unsigned safe = (R > 1) ? ((unsigned)strip * (2u * VC) + 2u * xp) * 4u : (unsigned)col * 4u;
+    const unsigned safe = (R > 1) ? ((unsigned)strip * (4u * VC) + 2u * xp) * 4u : (unsigned)col * 4u;
     const unsigned csafe = ((unsigned)strip * (unsigned)h * VC + 2u * xp) * 4u;
     {
         // Rows past the end of the column are loaded from row 0 of the same column (always inside the
@@ -108,7 +112,7 @@ __global__ void __launch_bounds__(VT) wave_vpass_kernel(WavePassArgs a)
             c[i] = *reinterpret_cast<const v2f*>(bC + (ok ? coff : csafe));
             f0[i] = *reinterpret_cast<const v2f*>(b0 + vo);
             f1[i] = (R > 1) ? *reinterpret_cast<const v2f*>(b1 + vo) : vsplat(0.0f);
-            voff += pitch_b; coff += pitch_c;
+            voff += ADF_VSTEP(i); coff += pitch_c;
             ADF_STEP_FENCE();   // one row's addresses at a time: hoisting all of them costs 2 registers per row
         }
 #pragma unroll
@@ -173,7 +177,7 @@ __global__ void __launch_bounds__(VT) wave_vpass_kernel(WavePassArgs a)
                 *reinterpret_cast<v2f*>(b0 + voff) = f0[i];
                 if (R > 1) *reinterpret_cast<v2f*>(b1 + voff) = f1[i];
             }
-            voff += pitch_b;
+            voff += ADF_VSTEP(i);
         }
     } else {
         char* ob = reinterpret_cast<char*>(a.out) + (ptrdiff_t)blockIdx.y * a.out_pair_stride +
