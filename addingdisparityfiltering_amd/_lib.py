@@ -77,6 +77,12 @@ SYMBOLS = [
     ("adf_compute_bad_pixel_percent_device", _i, [_vp, _pd, _vp, _pd, _i, _i, C.POINTER(Rect), _i, C.POINTER(_d), _vp]),
     ("adf_get_disparity_vis_host", _i, [_vp, _pd, _vp, _pd, _i, _i, _d]),
     ("adf_get_disparity_vis_device", _i, [_vp, _pd, _vp, _pd, _i, _i, _d, _vp]),
+    ("adf_bm_create", _i, [C.POINTER(_vp), _i, _i]),
+    ("adf_bm_destroy", None, [_vp]),
+    ("adf_bm_set_params", _i, [_vp, _i, _i, _i, _i, _i, _i]),
+    ("adf_bm_get_params", _i, [_vp] + [C.POINTER(_i)] * 6),
+    ("adf_bm_compute_device", _i, [_vp, _i, _vp, _pd, _pd, _vp, _pd, _pd, _i, _i, _vp, _pd, _pd, _vp]),
+    ("adf_bm_compute_host", _i, [_vp, _i, _vp, _pd, _pd, _vp, _pd, _pd, _i, _i, _vp, _pd, _pd]),
 ]
 
 _lib = None

@@ -14,6 +14,7 @@ SOURCES = {
     "fgs_wave_v.hip": ["-fno-slp-vectorize"],  # see the file header
     "eval_kernels.hip": [],
     "resize_kernels.hip": [],
+    "bm_matcher.hip": [],
 }
 HEADERS = ["adf_internal.h", "fgs_wave_common.h"]
 OUT = os.path.join(_HERE, "libadf_wls.so")

@@ -1,0 +1,422 @@
+// bm_matcher.hip -- block matcher on the device, so a stereo pair can go from views to filtered disparity
+// without leaving HBM.
+//
+// The reference's filter is fed by cv::StereoBM / cv::StereoSGBM (disparity_filters.cpp:386-449, sample
+// disparity_filtering.cpp:151,214), which live in OpenCV's calib3d module and are NOT in the reference tree:
+// PARITY UNPINNED at that boundary.  This file implements the published StereoBM algorithm exactly as
+// oracle/adf_oracle_bm.c states it (x-Sobel prefilter, SAD block matching, ties to the largest disparity,
+// texture / uniqueness tests, sub-pixel fit, 4 fractional bits), bit for bit -- it is integer work -- and keeps
+// the conventions the reference does fix: the parameters of the right-view matcher (:421-431) and the
+// settings the filter factory forces on the matcher (:389-390, 399-400).
+//
+// Layout.  The prefiltered views are stored "row-group interleaved": dword (g, x) holds the four
+// vertically adjacent pixels (x, 4g .. 4g+3) of column x, one byte each, as value+1 (so no byte is 0); PG
+// groups of replicated rows pad the top and the bottom.  One v_sad_u8 / v_msad_u8 then adds four rows of one
+// column of the SAD window, and a lane = one column reads consecutive dwords along a row of groups.
+//
+// Kernel.  One wave = 64 adjacent columns (the outer W2 on each side are window halo) x one group of four
+// output rows; the four waves of a workgroup take four consecutive row groups.  Per disparity a lane forms
+// the four vertical window sums of its column (groups fully inside all four windows are summed once, the
+// partial ones through v_msad_u8 with the rows outside the window zeroed in the left operand), two
+// disparities are packed in one register (low / high half; a window sum is below 2^16), an inclusive wave
+// scan (DPP) and the difference of two permuted prefix values give the horizontal window sums, and the
+// winner with its two neighbours (and, for the uniqueness test, the smallest cost away from the winner) is
+// tracked in registers while the disparities stream by.  Nothing but the int16 result is written.
+// The kernel is VALU-bound (about 20 lane-operations per pixel and disparity), not HBM-bound: the views are
+// read through L1/L2 once per disparity, HBM sees them once.
+#include "adf_internal.h"
+#include "../../include/adf_wls.h"
+
+#include <new>
+
+namespace {
+
+constexpr int PG = 3;        // padding groups above and below (half windows up to 10 rows)
+constexpr unsigned INF = 0x7fffffffu;
+
+struct PrefilterArgs {
+    const uint8_t* src; ptrdiff_t stride, pair_stride;
+    uint32_t* dst; size_t dst_pair;   // dwords per view
+    int W, H, HGP, cap;
+};
+
+// x-Sobel, clipped to [-cap, cap] and offset by cap (oracle: adf_oracle_bm_prefilter_xsobel); stored +1.
+__global__ void __launch_bounds__(256) bm_prefilter_kernel(PrefilterArgs a)
+{
+    const int x = blockIdx.x * 256 + threadIdx.x, gp = blockIdx.y;
+    if (x >= a.W) return;
+    const uint8_t* src = a.src + (ptrdiff_t)blockIdx.z * a.pair_stride;
+    uint32_t out = 0;
+#pragma unroll
+    for (int b = 0; b < 4; b++) {
+        const int y = min(max(4 * (gp - PG) + b, 0), a.H - 1);
+        int v = a.cap;
+        if (x > 0 && x < a.W - 1) {
+            const uint8_t* r0 = src + (ptrdiff_t)(y > 0 ? y - 1 : (a.H > 1 ? 1 : 0)) * a.stride;
+            const uint8_t* r1 = src + (ptrdiff_t)y * a.stride;
+            const uint8_t* r2 = src + (ptrdiff_t)(y < a.H - 1 ? y + 1 : (a.H > 1 ? a.H - 2 : 0)) * a.stride;
+            const int s = ((int)r0[x + 1] - (int)r0[x - 1]) + 2 * ((int)r1[x + 1] - (int)r1[x - 1]) + ((int)r2[x + 1] - (int)r2[x - 1]);
+            v = min(max(s, -a.cap), a.cap) + a.cap;
+        }
+        out |= (uint32_t)(v + 1) << (8 * b);
+    }
+    a.dst[(size_t)blockIdx.z * a.dst_pair + (size_t)gp * a.W + x] = out;
+}
+
+struct MatchArgs {
+    const uint32_t* Lt; const uint32_t* Rt; size_t t_pair;   // prefiltered views, dwords per view
+    int16_t* disp; ptrdiff_t dstride, dpair;                 // bytes
+    int W, H, HG;
+    int mindisp, ndisp;
+    int xs, xe;            // matched columns [xs, xe)
+    int cap, texthr, uniq;
+};
+
+// rows of group gi (relative to the output group) that lie in the window of output row r
+constexpr uint32_t window_mask(int W2, int GB, int gi, int r)
+{
+    uint32_t m = 0;
+    for (int b = 0; b < 4; b++) {
+        const int rel = 4 * (gi - GB) + b - r;
+        if (rel >= -W2 && rel <= W2) m |= 0xFFu << (8 * b);
+    }
+    return m;
+}
+constexpr bool group_common(int W2, int GB, int gi)
+{
+    for (int r = 0; r < 4; r++) if (window_mask(W2, GB, gi, r) != 0xFFFFFFFFu) return false;
+    return true;
+}
+
+template <int CTRL, int ROWMASK, bool BOUND>
+__device__ __forceinline__ uint32_t dpp_add(uint32_t v)
+{
+    return v + (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, ROWMASK, 0xF, BOUND);
+}
+// inclusive prefix sum over the 64 lanes of the wave
+__device__ __forceinline__ uint32_t wave_scan(uint32_t v)
+{
+    v = dpp_add<0x111, 0xF, true>(v);   // row_shr:1
+    v = dpp_add<0x112, 0xF, true>(v);   // row_shr:2
+    v = dpp_add<0x114, 0xF, true>(v);   // row_shr:4
+    v = dpp_add<0x118, 0xF, true>(v);   // row_shr:8
+    v = dpp_add<0x142, 0xA, false>(v);  // row_bcast:15 into rows 1 and 3
+    v = dpp_add<0x143, 0xC, false>(v);  // row_bcast:31 into rows 2 and 3
+    return v;
+}
+
+template <int W2, bool UNIQ>
+__global__ void __launch_bounds__(256) bm_match_kernel(MatchArgs a)
+{
+    constexpr int TOUT = 64 - 2 * W2;
+    constexpr int GB = (W2 + 3) / 4;        // groups above the output group that the windows reach
+    constexpr int NG = 2 * GB + 1;
+    static_assert(GB <= PG, "padding too small for this window");
+
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int g = blockIdx.y * 4 + wave;
+    if (g >= a.HG) return;                                           // whole wave; no barrier below
+    const int c = a.xs + (int)blockIdx.x * TOUT - W2 + lane;         // this lane's column
+    const size_t voff = (size_t)blockIdx.z * a.t_pair + (size_t)(g - GB + PG) * a.W;
+    const uint32_t* __restrict__ Lt = a.Lt + voff;
+    const uint32_t* __restrict__ Rt = a.Rt + voff;
+    const int W = a.W;
+
+    uint32_t Ld[NG];
+    {
+        const int cl = min(max(c, 0), W - 1);
+#pragma unroll
+        for (int gi = 0; gi < NG; gi++) Ld[gi] = Lt[(size_t)gi * W + cl];
+    }
+    // four vertical window sums (one per output row of the group) of |L - R| down this lane's column
+    auto vertical = [&](const uint32_t (&Rd)[NG], uint32_t (&V)[4]) {
+        uint32_t F = 0;
+#pragma unroll
+        for (int gi = 0; gi < NG; gi++)
+            if (group_common(W2, GB, gi)) F = __builtin_amdgcn_sad_u8(Rd[gi], Ld[gi], F);
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            uint32_t acc = F;
+#pragma unroll
+            for (int gi = 0; gi < NG; gi++) {
+                constexpr uint32_t dummy = 0; (void)dummy;
+                const uint32_t m = window_mask(W2, GB, gi, r);
+                if (group_common(W2, GB, gi) || m == 0) continue;
+                if (m == 0xFFFFFFFFu) acc = __builtin_amdgcn_sad_u8(Rd[gi], Ld[gi], acc);
+                else acc = __builtin_amdgcn_msad_u8(Rd[gi], Ld[gi] & m, acc);   // rows with a zero reference byte are skipped
+            }
+            V[r] = acc;
+        }
+    };
+    // horizontal window sum of a per-lane value: P(lane+W2) - P(lane-W2-1) of the inclusive wave prefix
+    const int hi_addr = min(lane + W2, 63) * 4, lo_addr = max(lane - W2 - 1, 0) * 4;
+    const bool lo_zero = lane - W2 - 1 < 0;
+    auto horizontal = [&](uint32_t v) -> uint32_t {
+        const uint32_t P = wave_scan(v);
+        const uint32_t ph = (uint32_t)__builtin_amdgcn_ds_bpermute(hi_addr, (int)P);
+        const uint32_t pl = (uint32_t)__builtin_amdgcn_ds_bpermute(lo_addr, (int)P);
+        return ph - (lo_zero ? 0u : pl);
+    };
+
+    // texture of the window: sum of |L - cap| (only needed with a texture threshold)
+    uint32_t tex[4] = {INF, INF, INF, INF};
+    if (a.texthr > 0) {
+        uint32_t Rd[NG], V[4];
+        const uint32_t ft = (uint32_t)(a.cap + 1) * 0x01010101u;
+#pragma unroll
+        for (int gi = 0; gi < NG; gi++) Rd[gi] = ft;
+        vertical(Rd, V);
+#pragma unroll
+        for (int r = 0; r < 4; r++) tex[r] = horizontal(V[r]);
+    }
+
+    uint32_t best[4], bk[4], pAt[4], nAt[4], prev[4];
+    uint32_t lmin[4], rmin[4], pm1[4], pm2[4];
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+        best[r] = INF; bk[r] = 0x40000000u; pAt[r] = INF; nAt[r] = INF; prev[r] = INF;
+        lmin[r] = INF; rmin[r] = INF; pm1[r] = INF; pm2[r] = INF;
+    }
+    auto track = [&](int r, uint32_t k, uint32_t s) {
+        const bool above = bk[r] + 1 == k;                 // k is one above the current winner
+        if (above) nAt[r] = s;
+        const bool upd = s <= best[r];                      // ties go to the larger disparity
+        if (UNIQ) {
+            if (!upd && !above) rmin[r] = min(rmin[r], s);
+            if (upd) { lmin[r] = pm2[r]; rmin[r] = INF; }
+            pm2[r] = pm1[r]; pm1[r] = min(pm1[r], s);
+        }
+        if (upd) { pAt[r] = prev[r]; best[r] = s; bk[r] = k; }
+        prev[r] = s;
+    };
+
+    const int xbase = c - a.mindisp;
+    for (int k = 0; k < a.ndisp; k += 2) {
+        uint32_t R0[NG], R1[NG], V0[4], V1[4];
+        const int x0 = min(max(xbase - k, 0), W - 1), x1 = min(max(xbase - k - 1, 0), W - 1);
+#pragma unroll
+        for (int gi = 0; gi < NG; gi++) { R0[gi] = Rt[(size_t)gi * W + x0]; R1[gi] = Rt[(size_t)gi * W + x1]; }
+        vertical(R0, V0);
+        vertical(R1, V1);
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const uint32_t Hs = horizontal(V0[r] + (V1[r] << 16));   // exact: both halves stay below 2^16
+            track(r, (uint32_t)k, Hs & 0xFFFFu);
+            track(r, (uint32_t)k + 1u, Hs >> 16);
+        }
+    }
+
+    const bool lane_ok = lane >= W2 && lane < 64 - W2 && c < a.xe;
+    const int16_t filtered = (int16_t)((a.mindisp - 1) * 16);
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+        const int y = 4 * g + r;
+        if (y >= a.H || !lane_ok) continue;
+        const int kb = (int)bk[r], sb = (int)best[r];
+        const int pv = (int)(kb > 0 ? pAt[r] : nAt[r]);
+        const int nv = (int)(kb < a.ndisp - 1 ? nAt[r] : pAt[r]);
+        const int dd = pv + nv - 2 * sb + abs(pv - nv);
+        int16_t out = (int16_t)(((kb + a.mindisp) * 256 + (dd != 0 ? (pv - nv) * 256 / dd : 0) + 15) >> 4);
+        if ((int)tex[r] < a.texthr) out = filtered;
+        if (UNIQ) {
+            const int thresh = sb + sb * a.uniq / 100;
+            if ((int)min(lmin[r], rmin[r]) <= thresh) out = filtered;
+        }
+        *reinterpret_cast<int16_t*>(reinterpret_cast<char*>(a.disp) + (ptrdiff_t)blockIdx.z * a.dpair + (ptrdiff_t)y * a.dstride + (ptrdiff_t)c * 2) = out;
+    }
+}
+
+// columns without a full search range or window: (minDisparity - 1) * 16
+__global__ void __launch_bounds__(256) bm_border_kernel(MatchArgs a)
+{
+    const int y = blockIdx.y;
+    const int nleft = max(min(a.xs, a.W), 0), xr = (a.xe > a.xs) ? max(a.xe, nleft) : nleft;
+    const int n = nleft + (a.W - xr);
+    const int16_t filtered = (int16_t)((a.mindisp - 1) * 16);
+    int16_t* row = reinterpret_cast<int16_t*>(reinterpret_cast<char*>(a.disp) + (ptrdiff_t)blockIdx.z * a.dpair + (ptrdiff_t)y * a.dstride);
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) row[i < nleft ? i : xr + (i - nleft)] = filtered;
+}
+
+template <bool UNIQ>
+hipError_t launch_match(const MatchArgs& a, int w2, dim3 block, int n, hipStream_t st)
+{
+    const int tout = 64 - 2 * w2;
+    dim3 grid((a.xe - a.xs + tout - 1) / tout, (a.HG + 3) / 4, n);
+    switch (w2) {
+#define ADF_BM_CASE(K) case K: hipLaunchKernelGGL((bm_match_kernel<K, UNIQ>), grid, block, 0, st, a); break;
+    ADF_BM_CASE(2) ADF_BM_CASE(3) ADF_BM_CASE(4) ADF_BM_CASE(5) ADF_BM_CASE(6)
+    ADF_BM_CASE(7) ADF_BM_CASE(8) ADF_BM_CASE(9) ADF_BM_CASE(10)
+#undef ADF_BM_CASE
+    default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
+
+} // namespace
+
+// ----------------------------------------------------------------------------------------------
+// C-ABI (include/adf_wls.h, "block matcher")
+// ----------------------------------------------------------------------------------------------
+struct adf_bm {
+    int device = 0;
+    int min_disp = 0, num_disp = 0, block = 21;
+    int cap = 31, texthr = 10, uniq = 15;       // cv::StereoBM's defaults
+    void* views = nullptr; size_t views_bytes = 0;   // prefiltered left + right views of the batch
+    void* stage = nullptr; size_t stage_bytes = 0;   // host-pointer entry: device copies of the I/O
+};
+
+namespace {
+int bm_fail(int code, const char* msg) { return adf::set_error(code, msg); }
+int reserve(void** p, size_t* have, size_t need, hipStream_t st)
+{
+    if (need <= *have) return ADF_OK;
+    if (*p) { if (hipStreamSynchronize(st) != hipSuccess) return bm_fail(ADF_EHIP, "hipStreamSynchronize failed"); hipFree(*p); *p = nullptr; *have = 0; }
+    need = (need + 255) / 256 * 256;
+    hipError_t e = hipMalloc(p, need);
+    if (e != hipSuccess) { *p = nullptr; return bm_fail(e == hipErrorOutOfMemory ? ADF_ENOMEM : ADF_EHIP, "hipMalloc failed for the matcher workspace"); }
+    *have = need;
+    return ADF_OK;
+}
+struct DevScope {
+    int prev = -1; bool sw = false;
+    explicit DevScope(int d) { if (hipGetDevice(&prev) == hipSuccess && prev != d) sw = hipSetDevice(d) == hipSuccess; }
+    ~DevScope() { if (sw) hipSetDevice(prev); }
+};
+} // namespace
+
+extern "C" int adf_bm_create(adf_bm_t** out, int num_disparities, int block_size)
+{
+    if (!out) return bm_fail(ADF_EBADARG, "out is NULL");
+    *out = nullptr;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return bm_fail(ADF_ENODEV, "no HIP device");
+    adf_bm* h = new (std::nothrow) adf_bm;
+    if (!h) return bm_fail(ADF_ENOMEM, "out of host memory");
+    h->device = dev; h->num_disp = num_disparities; h->block = block_size;
+    *out = h;
+    return ADF_OK;
+}
+
+extern "C" void adf_bm_destroy(adf_bm_t* h)
+{
+    if (!h) return;
+    DevScope ds(h->device);
+    if (h->views) hipFree(h->views);
+    if (h->stage) hipFree(h->stage);
+    delete h;
+}
+
+extern "C" int adf_bm_set_params(adf_bm_t* h, int min_disparity, int num_disparities, int block_size,
+                                 int prefilter_cap, int texture_threshold, int uniqueness_ratio)
+{
+    if (!h) return bm_fail(ADF_EBADARG, "handle is NULL");
+    h->min_disp = min_disparity; h->num_disp = num_disparities; h->block = block_size;
+    h->cap = prefilter_cap; h->texthr = texture_threshold; h->uniq = uniqueness_ratio;
+    return ADF_OK;
+}
+
+extern "C" int adf_bm_get_params(const adf_bm_t* h, int* min_disparity, int* num_disparities, int* block_size,
+                                 int* prefilter_cap, int* texture_threshold, int* uniqueness_ratio)
+{
+    if (!h) return bm_fail(ADF_EBADARG, "handle is NULL");
+    if (min_disparity) *min_disparity = h->min_disp;
+    if (num_disparities) *num_disparities = h->num_disp;
+    if (block_size) *block_size = h->block;
+    if (prefilter_cap) *prefilter_cap = h->cap;
+    if (texture_threshold) *texture_threshold = h->texthr;
+    if (uniqueness_ratio) *uniqueness_ratio = h->uniq;
+    return ADF_OK;
+}
+
+static int bm_check(const adf_bm* h, int n, const void* l, const void* r, const void* d, int W, int H,
+                    ptrdiff_t ls, ptrdiff_t rs, ptrdiff_t dstr)
+{
+    if (!h) return bm_fail(ADF_EBADARG, "handle is NULL");
+    if (n <= 0 || !l || !r || !d) return bm_fail(ADF_EBADARG, "views and disparity must be non-NULL, n_pairs positive");
+    if (W <= 0 || H <= 0 || ls < W || rs < W || dstr < (ptrdiff_t)W * 2) return bm_fail(ADF_ESIZE, "bad size or stride");
+    // the checks cv::StereoBM::compute makes on its parameters; the window is limited to 21 so that a
+    // window sum fits 16 bits
+    if (h->num_disp <= 0 || h->num_disp % 16) return bm_fail(ADF_EBADARG, "numDisparities must be positive and divisible by 16");
+    if (h->block < 5 || h->block > 21 || h->block % 2 == 0) return bm_fail(ADF_EBADARG, "blockSize must be odd and within 5..21");
+    if (h->block >= (W < H ? W : H)) return bm_fail(ADF_EBADARG, "blockSize must be smaller than the image");
+    if (h->cap < 1 || h->cap > 63) return bm_fail(ADF_EBADARG, "preFilterCap must be within 1..63");
+    if (h->texthr < 0 || h->uniq < 0) return bm_fail(ADF_EBADARG, "textureThreshold and uniquenessRatio must be non-negative");
+    if (h->min_disp < -32768 || h->min_disp + h->num_disp > 2047) return bm_fail(ADF_EBADARG, "disparity range does not fit CV_16S with 4 fractional bits");
+    return ADF_OK;
+}
+
+extern "C" int adf_bm_compute_device(adf_bm_t* h, int n_pairs,
+                                     const uint8_t* left, ptrdiff_t left_stride, ptrdiff_t left_pair_stride,
+                                     const uint8_t* right, ptrdiff_t right_stride, ptrdiff_t right_pair_stride,
+                                     int W, int H,
+                                     int16_t* disparity, ptrdiff_t disp_stride, ptrdiff_t disp_pair_stride,
+                                     void* stream)
+{
+    int rc = bm_check(h, n_pairs, left, right, disparity, W, H, left_stride, right_stride, disp_stride);
+    if (rc) return rc;
+    DevScope ds(h->device);
+    hipStream_t st = (hipStream_t)stream;
+    const int HG = (H + 3) / 4, HGP = HG + 2 * PG;
+    const size_t view = (size_t)HGP * W;                       // dwords per prefiltered view
+    rc = reserve(&h->views, &h->views_bytes, 2 * view * (size_t)n_pairs * sizeof(uint32_t), st);
+    if (rc) return rc;
+    uint32_t* Lt = (uint32_t*)h->views;
+    uint32_t* Rt = Lt + view * (size_t)n_pairs;
+
+    PrefilterArgs p;
+    p.W = W; p.H = H; p.HGP = HGP; p.cap = h->cap; p.dst_pair = view;
+    dim3 pgrid((W + 255) / 256, HGP, n_pairs);
+    p.src = left; p.stride = left_stride; p.pair_stride = left_pair_stride; p.dst = Lt;
+    hipLaunchKernelGGL(bm_prefilter_kernel, pgrid, dim3(256), 0, st, p);
+    p.src = right; p.stride = right_stride; p.pair_stride = right_pair_stride; p.dst = Rt;
+    hipLaunchKernelGGL(bm_prefilter_kernel, pgrid, dim3(256), 0, st, p);
+
+    MatchArgs a;
+    a.Lt = Lt; a.Rt = Rt; a.t_pair = view;
+    a.disp = disparity; a.dstride = disp_stride; a.dpair = disp_pair_stride;
+    a.W = W; a.H = H; a.HG = HG;
+    a.mindisp = h->min_disp; a.ndisp = h->num_disp;
+    const int w2 = h->block / 2, maxd = h->min_disp + h->num_disp - 1;
+    a.xs = (maxd > 0 ? maxd : 0) + w2;
+    a.xe = W - (h->min_disp < 0 ? -h->min_disp : 0) - w2;
+    a.cap = h->cap; a.texthr = h->texthr; a.uniq = h->uniq;
+    hipLaunchKernelGGL(bm_border_kernel, dim3(4, H, n_pairs), dim3(256), 0, st, a);
+    if (a.xe > a.xs) {
+        hipError_t e = h->uniq > 0 ? launch_match<true>(a, w2, dim3(256), n_pairs, st)
+                                   : launch_match<false>(a, w2, dim3(256), n_pairs, st);
+        if (e != hipSuccess) return bm_fail(ADF_EHIP, hipGetErrorString(e));
+    }
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return bm_fail(ADF_EHIP, hipGetErrorString(e));
+    return ADF_OK;
+}
+
+extern "C" int adf_bm_compute_host(adf_bm_t* h, int n_pairs,
+                                   const uint8_t* left, ptrdiff_t left_stride, ptrdiff_t left_pair_stride,
+                                   const uint8_t* right, ptrdiff_t right_stride, ptrdiff_t right_pair_stride,
+                                   int W, int H,
+                                   int16_t* disparity, ptrdiff_t disp_stride, ptrdiff_t disp_pair_stride)
+{
+    int rc = bm_check(h, n_pairs, left, right, disparity, W, H, left_stride, right_stride, disp_stride);
+    if (rc) return rc;
+    DevScope ds(h->device);
+    const size_t vbytes = (size_t)W * H, dbytes = (size_t)W * H * 2;
+    rc = reserve(&h->stage, &h->stage_bytes, (2 * vbytes + dbytes) * (size_t)n_pairs, nullptr);
+    if (rc) return rc;
+    uint8_t* dl = (uint8_t*)h->stage;
+    uint8_t* dr = dl + vbytes * n_pairs;
+    int16_t* dd = (int16_t*)(dr + vbytes * n_pairs);
+    for (int i = 0; i < n_pairs; i++) {
+        if (hipMemcpy2D(dl + vbytes * i, W, left + (ptrdiff_t)i * left_pair_stride, left_stride, W, H, hipMemcpyHostToDevice) != hipSuccess ||
+            hipMemcpy2D(dr + vbytes * i, W, right + (ptrdiff_t)i * right_pair_stride, right_stride, W, H, hipMemcpyHostToDevice) != hipSuccess)
+            return bm_fail(ADF_EHIP, "copying the views to the device failed");
+    }
+    rc = adf_bm_compute_device(h, n_pairs, dl, W, (ptrdiff_t)vbytes, dr, W, (ptrdiff_t)vbytes, W, H, dd, (ptrdiff_t)W * 2, (ptrdiff_t)dbytes, nullptr);
+    if (rc) return rc;
+    if (hipStreamSynchronize(nullptr) != hipSuccess) return bm_fail(ADF_EHIP, "the matcher kernels failed");
+    for (int i = 0; i < n_pairs; i++)
+        if (hipMemcpy2D(reinterpret_cast<char*>(disparity) + (ptrdiff_t)i * disp_pair_stride, disp_stride, dd + (size_t)W * H * i, (size_t)W * 2,
+                        (size_t)W * 2, H, hipMemcpyDeviceToHost) != hipSuccess)
+            return bm_fail(ADF_EHIP, "copying the disparity map back failed");
+    return ADF_OK;
+}

@@ -268,8 +268,10 @@ class DisparityWLSFilter(DisparityFilter):
 
 
 # ---------------------------------------------------------------------------------------------
-# Matchers.  cv::StereoBM / cv::StereoSGBM live in OpenCV's calib3d, which is outside this path;
-# the factories below only need the parameter accessors, so a plain parameter holder stands in.
+# Matchers.  cv::StereoBM / cv::StereoSGBM live in OpenCV's calib3d, which is outside the reference tree;
+# the factories below only need the parameter accessors.  StereoBM additionally carries compute(), the
+# published block-matching algorithm on the device (csrc/bm_matcher.hip; parity unpinned
+# at the calib3d boundary, bit-exact against oracle/adf_oracle_bm.c); StereoSGBM is a parameter holder only.
 # ---------------------------------------------------------------------------------------------
 class StereoMatcher:
     def __init__(self, minDisparity=0, numDisparities=16, blockSize=3):
@@ -279,22 +281,75 @@ class StereoMatcher:
     def getMinDisparity(self): return self.minDisparity
     def setMinDisparity(self, v): self.minDisparity = v
     def getNumDisparities(self): return self.numDisparities
+    def setNumDisparities(self, v): self.numDisparities = v
     def getBlockSize(self): return self.blockSize
+    def setBlockSize(self, v): self.blockSize = v
+    def getDisp12MaxDiff(self): return self.disp12MaxDiff
     def setDisp12MaxDiff(self, v): self.disp12MaxDiff = v
+    def getSpeckleWindowSize(self): return self.speckleWindowSize
     def setSpeckleWindowSize(self, v): self.speckleWindowSize = v
+    def getUniquenessRatio(self): return self.uniquenessRatio
     def setUniquenessRatio(self, v): self.uniquenessRatio = v
 
 
 class StereoBM(StereoMatcher):
     def __init__(self, numDisparities=0, blockSize=21):
-        super().__init__(0, numDisparities, blockSize)
-        self.textureThreshold = 10
+        super().__init__(0, numDisparities if numDisparities > 0 else 64, blockSize)   # cv::StereoBM: 0 -> 64
+        self.textureThreshold, self.uniquenessRatio, self.preFilterCap = 10, 15, 31
+        self._h = None
 
     @staticmethod
     def create(numDisparities=0, blockSize=21):
         return StereoBM(numDisparities, blockSize)
 
+    def __del__(self):
+        h, self._h = getattr(self, "_h", None), None
+        if h:
+            try:
+                _lib.lib().adf_bm_destroy(h)
+            except Exception:
+                pass
+
+    def getTextureThreshold(self): return self.textureThreshold
     def setTextureThreshold(self, v): self.textureThreshold = v
+    def getPreFilterCap(self): return self.preFilterCap
+    def setPreFilterCap(self, v): self.preFilterCap = v
+
+    def compute(self, left, right, disparity=None):
+        """StereoMatcher::compute: CV_8UC1 views (H,W) or a batch (N,H,W) -> CV_16SC1 disparity*16, rejected
+        pixels (minDisparity-1)*16.  torch CUDA tensors are matched where they are, asynchronously on torch's
+        current stream; numpy arrays take the host entry point.  The left-right check and the speckle filter
+        of cv::StereoBM are not implemented: the filter factory switches both off (DF.cpp:389-390)."""
+        if self.disp12MaxDiff >= 0 and self.disp12MaxDiff < 1000000:
+            raise AdfError(_lib.ADF_EBADARG, "disp12MaxDiff (left-right check inside the matcher) is not implemented")
+        if self.speckleWindowSize > 0:
+            raise AdfError(_lib.ADF_EBADARG, "speckle filtering is not implemented")
+        batched = len(left.shape) == 3
+        L = _Image(left, np.uint8, "left", batched)
+        R = _Image(right, np.uint8, "right", batched)
+        if (L.n, L.h, L.w) != (R.n, R.h, R.w):
+            raise AdfError(_lib.ADF_ESIZE, "All the images must have the same size")
+        if L.device != R.device:
+            raise AdfError(_lib.ADF_EBADARG, "left and right must live on the same side (host or device)")
+        if disparity is None:
+            disparity = _out_like(L, batched, np.int16)
+        D = _Image(disparity, np.int16, "disparity", batched)
+        if (D.n, D.h, D.w) != (L.n, L.h, L.w) or D.device != L.device:
+            raise AdfError(_lib.ADF_ESIZE, "disparity must match the views")
+        lib = _lib.lib()
+        if self._h is None:
+            h = C.c_void_p()
+            _lib.check(lib.adf_bm_create(C.byref(h), int(self.numDisparities), int(self.blockSize)))
+            self._h = h
+        _lib.check(lib.adf_bm_set_params(self._h, int(self.minDisparity), int(self.numDisparities), int(self.blockSize),
+                                         int(self.preFilterCap), int(self.textureThreshold), int(self.uniquenessRatio)))
+        args = [self._h, L.n, C.c_void_p(L.ptr), L.stride, L.pair_stride, C.c_void_p(R.ptr), R.stride, R.pair_stride,
+                L.w, L.h, C.c_void_p(D.ptr), D.stride, D.pair_stride]
+        if L.device:
+            _lib.check(lib.adf_bm_compute_device(*args, _stream_of(L)))
+        else:
+            _lib.check(lib.adf_bm_compute_host(*args))
+        return disparity
 
 
 class StereoSGBM(StereoMatcher):

@@ -221,6 +221,40 @@ int adf_get_disparity_vis_host(const int16_t* src, ptrdiff_t src_stride, uint8_t
 int adf_get_disparity_vis_device(const int16_t* src, ptrdiff_t src_stride, uint8_t* dst, ptrdiff_t dst_stride,
                                  int W, int H, double scale, void* stream);
 
+/* ---------------- block matcher feeding the filter ----------------
+ * The reference's filter takes its maps from cv::StereoBM / cv::StereoSGBM (disparity_filters.cpp:386-449,
+ * samples/disparity_filtering.cpp:151,214), classes of OpenCV's calib3d module that are not part of the
+ * reference tree (parity unpinned there).  adf_bm_* is the published StereoBM algorithm on the device --
+ * x-Sobel prefilter, SAD block matching, sub-pixel fit, CV_16SC1 output with 4 fractional bits, rejected
+ * pixels = (minDisparity-1)*16 -- so a pair can go from views to filtered disparity without leaving HBM.
+ * Bit-exact against oracle/adf_oracle_bm.c; pinned by the reference's own block-matching test data and
+ * accuracy bar (modules/stereo/test/test_block_matching.cpp:61-82,148).  Limits: blockSize 5..21. */
+typedef struct adf_bm adf_bm_t; /* cv::Ptr<StereoBM> */
+/* StereoBM::create(numDisparities, blockSize); other parameters start at cv::StereoBM's defaults
+ * (minDisparity 0, preFilterCap 31, textureThreshold 10, uniquenessRatio 15). */
+int adf_bm_create(adf_bm_t** out, int num_disparities, int block_size);
+void adf_bm_destroy(adf_bm_t* h);
+/* The StereoMatcher / StereoBM setters in one call (the filter factory forces textureThreshold = 0 and
+ * uniquenessRatio = 0, disparity_filters.cpp:399-400; the right-view matcher uses
+ * minDisparity = -(min_disp+num_disp)+1, :424).  Values are checked at compute time like cv::StereoBM. */
+int adf_bm_set_params(adf_bm_t* h, int min_disparity, int num_disparities, int block_size,
+                      int prefilter_cap, int texture_threshold, int uniqueness_ratio);
+int adf_bm_get_params(const adf_bm_t* h, int* min_disparity, int* num_disparities, int* block_size,
+                      int* prefilter_cap, int* texture_threshold, int* uniqueness_ratio);
+/* StereoMatcher::compute(left, right, disparity) on a batch of n_pairs equally sized CV_8UC1 pairs laid out
+ * `*_pair_stride` bytes apart; disparity: CV_16SC1, W x H (strides in bytes).  Asynchronous on `stream`. */
+int adf_bm_compute_device(adf_bm_t* h, int n_pairs,
+                          const uint8_t* left, ptrdiff_t left_stride, ptrdiff_t left_pair_stride,
+                          const uint8_t* right, ptrdiff_t right_stride, ptrdiff_t right_pair_stride,
+                          int W, int H,
+                          int16_t* disparity, ptrdiff_t disp_stride, ptrdiff_t disp_pair_stride,
+                          void* stream);
+int adf_bm_compute_host(adf_bm_t* h, int n_pairs,
+                        const uint8_t* left, ptrdiff_t left_stride, ptrdiff_t left_pair_stride,
+                        const uint8_t* right, ptrdiff_t right_stride, ptrdiff_t right_pair_stride,
+                        int W, int H,
+                        int16_t* disparity, ptrdiff_t disp_stride, ptrdiff_t disp_pair_stride);
+
 #ifdef __cplusplus
 }
 #endif

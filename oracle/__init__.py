@@ -32,9 +32,20 @@ class Params(C.Structure):
     ]
 
 
+class BMParams(C.Structure):
+    _fields_ = [
+        ("min_disparity", C.c_int),
+        ("num_disparities", C.c_int),
+        ("block_size", C.c_int),
+        ("prefilter_cap", C.c_int),
+        ("texture_threshold", C.c_int),
+        ("uniqueness_ratio", C.c_int),
+    ]
+
+
 def build(force=False):
     """Compile the oracle with gcc (oracle/Makefile)."""
-    src_m = max(os.path.getmtime(os.path.join(_HERE, f)) for f in ("adf_oracle.c", "adf_oracle.h"))
+    src_m = max(os.path.getmtime(os.path.join(_HERE, f)) for f in ("adf_oracle.c", "adf_oracle_bm.c", "adf_oracle.h"))
     if force or not os.path.exists(_LIB_PATH) or os.path.getmtime(_LIB_PATH) < src_m:
         subprocess.run(["make", "-C", _HERE, "-B", "libadf_oracle.so"], check=True,
                        stdout=subprocess.DEVNULL)
@@ -74,6 +85,9 @@ def lib():
         L.adf_oracle_resize_linear_32f.argtypes = [vp, i, i, vp, i, i]
         L.adf_oracle_wls_filter_scaled.argtypes = [C.POINTER(Params), vp, vp, i, i, vp, i, i, i, i, i, i, i, vp, vp]
         L.adf_oracle_wls_filter_scaled.restype = i
+        L.adf_oracle_bm_prefilter_xsobel.argtypes = [vp, pd, i, i, i, vp]
+        L.adf_oracle_bm_compute.argtypes = [C.POINTER(BMParams), vp, pd, vp, pd, i, i, vp, pd]
+        L.adf_oracle_bm_compute.restype = i
         L.adf_oracle_sat16.argtypes = [f]
         L.adf_oracle_sat16.restype = C.c_int16
         _lib = L
@@ -247,3 +261,26 @@ def wls_filter_scaled(dispL, guide, dispR, roi, params=None):
     if rc:
         raise ValueError("adf_oracle_wls_filter_scaled rc=%d" % rc)
     return out, conf
+
+
+def bm_prefilter_xsobel(img, cap=31):
+    img = np.ascontiguousarray(img, dtype=np.uint8)
+    H, W = img.shape
+    out = np.empty((H, W), np.uint8)
+    lib().adf_oracle_bm_prefilter_xsobel(_p(img), img.strides[0], W, H, cap, _p(out))
+    return out
+
+
+def bm_compute(left, right, num_disparities, block_size, min_disparity=0, prefilter_cap=31,
+               texture_threshold=0, uniqueness_ratio=0):
+    """Block matcher restated from the published StereoBM algorithm (adf_oracle_bm.c; parity unpinned)."""
+    left = np.ascontiguousarray(left, dtype=np.uint8)
+    right = np.ascontiguousarray(right, dtype=np.uint8)
+    assert left.shape == right.shape and left.ndim == 2
+    H, W = left.shape
+    out = np.empty((H, W), np.int16)
+    prm = BMParams(min_disparity, num_disparities, block_size, prefilter_cap, texture_threshold, uniqueness_ratio)
+    rc = lib().adf_oracle_bm_compute(C.byref(prm), _p(left), left.strides[0], _p(right), right.strides[0], W, H, _p(out), W)
+    if rc:
+        raise ValueError("adf_oracle_bm_compute: bad arguments (%d)" % rc)
+    return out

@@ -138,6 +138,22 @@ int adf_oracle_wls_filter_scaled(const adf_oracle_params* p, const int16_t* disp
  * exported so tests can probe the rounding convention directly. */
 int16_t adf_oracle_sat16(float v);
 
+/* ---- block matcher feeding the filter (adf_oracle_bm.c) ----
+ * cv::StereoBM is external to the reference (calib3d, unpinned): parity unpinned; see adf_oracle_bm.c. */
+typedef struct adf_oracle_bm_params {
+    int min_disparity;      /* StereoMatcher::setMinDisparity (right matcher: disparity_filters.cpp:424) */
+    int num_disparities;    /* multiple of 16 */
+    int block_size;         /* odd, 5..21 */
+    int prefilter_cap;      /* 1..63, StereoBM default 31 */
+    int texture_threshold;  /* forced to 0 by the filter factory (disparity_filters.cpp:399) */
+    int uniqueness_ratio;   /* forced to 0 by the filter factory (disparity_filters.cpp:400) */
+} adf_oracle_bm_params;
+void adf_oracle_bm_prefilter_xsobel(const uint8_t* src, ptrdiff_t stride, int W, int H, int cap, uint8_t* dst);
+/* left/right: CV_8UC1 W x H (strides in bytes); disp: CV_16SC1, stride in ELEMENTS. */
+int adf_oracle_bm_compute(const adf_oracle_bm_params* p, const uint8_t* left, ptrdiff_t lstride,
+                          const uint8_t* right, ptrdiff_t rstride, int W, int H,
+                          int16_t* disp, ptrdiff_t dstride);
+
 #ifdef __cplusplus
 }
 #endif

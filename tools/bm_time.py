@@ -1,0 +1,33 @@
+"""Times the device block matcher (both views) on synthetic pairs: python tools/bm_time.py [W H ndisp wsz n]"""
+import sys
+import time
+
+import numpy as np
+import torch
+
+sys.path.insert(0, ".")
+import addingdisparityfiltering_amd as adf
+
+W, H, nd, wsz, n = (int(v) for v in (sys.argv[1:6] + ["3840", "2160", "256", "15", "4"][len(sys.argv) - 1:]))
+rng = np.random.default_rng(0)
+base = rng.integers(0, 256, (n, H, W + 64), dtype=np.uint8)
+left = torch.from_numpy(np.ascontiguousarray(base[:, :, 32:32 + W])).cuda()
+right = torch.from_numpy(np.ascontiguousarray(np.roll(base, -9, 2)[:, :, 32:32 + W])).cuda()
+lm = adf.StereoBM.create(nd, wsz)
+lm.setTextureThreshold(0); lm.setUniquenessRatio(0)
+rm = adf.createRightMatcher(lm)
+dl = torch.empty((n, H, W), dtype=torch.int16, device="cuda")
+dr = torch.empty_like(dl)
+for _ in range(2):
+    lm.compute(left, right, dl); rm.compute(right, left, dr)
+torch.cuda.synchronize()
+e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+reps = 3
+e0.record()
+for _ in range(reps):
+    lm.compute(left, right, dl); rm.compute(right, left, dr)
+e1.record(); torch.cuda.synchronize()
+ms = e0.elapsed_time(e1) / reps
+px = n * W * H
+print("matcher both views: %dx%d ndisp %d block %d, %d pairs: %.2f ms  (%.3f ms/pair, %.2f Gpx/s, %.1f G(px*disp)/s per view)" %
+      (W, H, nd, wsz, n, ms, ms / n, px / ms / 1e6, 2 * px * nd / ms / 1e6))
