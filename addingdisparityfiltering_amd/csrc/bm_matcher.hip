@@ -37,7 +37,7 @@ constexpr unsigned INF = 0x7fffffffu;
 struct PrefilterArgs {
     const uint8_t* src; ptrdiff_t stride, pair_stride;
     uint32_t* dst; size_t dst_pair;   // dwords per view
-    int W, H, HGP, cap;
+    int W, Wp, H, HGP, cap;
 };
 
 // x-Sobel, clipped to [-cap, cap] and offset by cap (oracle: adf_oracle_bm_prefilter_xsobel); stored +1.
@@ -60,13 +60,13 @@ __global__ void __launch_bounds__(256) bm_prefilter_kernel(PrefilterArgs a)
         }
         out |= (uint32_t)(v + 1) << (8 * b);
     }
-    a.dst[(size_t)blockIdx.z * a.dst_pair + (size_t)gp * a.W + x] = out;
+    a.dst[(size_t)blockIdx.z * a.dst_pair + (size_t)gp * a.Wp + x] = out;
 }
 
 struct MatchArgs {
     const uint32_t* Lt; const uint32_t* Rt; size_t t_pair;   // prefiltered views, dwords per view
     int16_t* disp; ptrdiff_t dstride, dpair;                 // bytes
-    int W, H, HG;
+    int W, Wp, H, HG;                                        // Wp: dwords per prefiltered row (W + XPAD, multiple of 4)
     int mindisp, ndisp;
     int xs, xe;            // matched columns [xs, xe)
     int cap, texthr, uniq;
@@ -105,10 +105,15 @@ __device__ __forceinline__ uint32_t wave_scan(uint32_t v)
     return v;
 }
 
+constexpr int CPL = 4;                 // adjacent columns per lane
+constexpr int TILE = 64 * CPL;         // columns per wave, window halo included
+constexpr int XPAD = TILE + 4;         // columns of padding right of a prefiltered row (lanes past the image read it)
+constexpr int floordiv(int a, int b) { return (a >= 0) ? a / b : -((-a + b - 1) / b); }
+
 template <int W2, bool UNIQ>
 __global__ void __launch_bounds__(256) bm_match_kernel(MatchArgs a)
 {
-    constexpr int TOUT = 64 - 2 * W2;
+    constexpr int TOUT = TILE - 2 * W2;
     constexpr int GB = (W2 + 3) / 4;        // groups above the output group that the windows reach
     constexpr int NG = 2 * GB + 1;
     static_assert(GB <= PG, "padding too small for this window");
@@ -116,113 +121,172 @@ __global__ void __launch_bounds__(256) bm_match_kernel(MatchArgs a)
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int g = blockIdx.y * 4 + wave;
     if (g >= a.HG) return;                                           // whole wave; no barrier below
-    const int c = a.xs + (int)blockIdx.x * TOUT - W2 + lane;         // this lane's column
-    const size_t voff = (size_t)blockIdx.z * a.t_pair + (size_t)(g - GB + PG) * a.W;
+    const int c = a.xs + (int)blockIdx.x * TOUT - W2 + lane * CPL;   // this lane's first column (>= 0)
+    const int Wp = a.Wp;
+    const size_t voff = (size_t)blockIdx.z * a.t_pair + (size_t)(g - GB + PG) * Wp;
     const uint32_t* __restrict__ Lt = a.Lt + voff;
     const uint32_t* __restrict__ Rt = a.Rt + voff;
-    const int W = a.W;
 
-    uint32_t Ld[NG];
-    {
-        const int cl = min(max(c, 0), W - 1);
+    auto load4 = [&](const uint32_t* row, int x, uint32_t (&d)[CPL]) {   // x .. x+3 are inside the padded row
+        struct __attribute__((aligned(4))) Quad { uint32_t v[4]; };      // dword-aligned 16-byte load
+        const Quad q = *reinterpret_cast<const Quad*>(row + x);
+        d[0] = q.v[0]; d[1] = q.v[1]; d[2] = q.v[2]; d[3] = q.v[3];
+    };
+    const int cl = min(c, Wp - CPL);
+    uint32_t Ld[NG][CPL];
 #pragma unroll
-        for (int gi = 0; gi < NG; gi++) Ld[gi] = Lt[(size_t)gi * W + cl];
-    }
-    // four vertical window sums (one per output row of the group) of |L - R| down this lane's column
-    auto vertical = [&](const uint32_t (&Rd)[NG], uint32_t (&V)[4]) {
+    for (int gi = 0; gi < NG; gi++) load4(Lt + (size_t)gi * Wp, cl, Ld[gi]);
+
+    // four vertical window sums (one per output row of the group) of |L - R| down column j of this lane
+    auto vertical = [&](const uint32_t (&Rd)[NG][CPL], int j, uint32_t (&V)[4]) {
         uint32_t F = 0;
 #pragma unroll
         for (int gi = 0; gi < NG; gi++)
-            if (group_common(W2, GB, gi)) F = __builtin_amdgcn_sad_u8(Rd[gi], Ld[gi], F);
+            if (group_common(W2, GB, gi)) F = __builtin_amdgcn_sad_u8(Rd[gi][j], Ld[gi][j], F);
 #pragma unroll
         for (int r = 0; r < 4; r++) {
             uint32_t acc = F;
 #pragma unroll
             for (int gi = 0; gi < NG; gi++) {
-                constexpr uint32_t dummy = 0; (void)dummy;
                 const uint32_t m = window_mask(W2, GB, gi, r);
                 if (group_common(W2, GB, gi) || m == 0) continue;
-                if (m == 0xFFFFFFFFu) acc = __builtin_amdgcn_sad_u8(Rd[gi], Ld[gi], acc);
-                else acc = __builtin_amdgcn_msad_u8(Rd[gi], Ld[gi] & m, acc);   // rows with a zero reference byte are skipped
+                if (m == 0xFFFFFFFFu) acc = __builtin_amdgcn_sad_u8(Rd[gi][j], Ld[gi][j], acc);
+                else acc = __builtin_amdgcn_msad_u8(Rd[gi][j], Ld[gi][j] & m, acc);   // rows with a zero reference byte are skipped
             }
             V[r] = acc;
         }
     };
-    // horizontal window sum of a per-lane value: P(lane+W2) - P(lane-W2-1) of the inclusive wave prefix
-    const int hi_addr = min(lane + W2, 63) * 4, lo_addr = max(lane - W2 - 1, 0) * 4;
-    const bool lo_zero = lane - W2 - 1 < 0;
-    auto horizontal = [&](uint32_t v) -> uint32_t {
-        const uint32_t P = wave_scan(v);
-        const uint32_t ph = (uint32_t)__builtin_amdgcn_ds_bpermute(hi_addr, (int)P);
-        const uint32_t pl = (uint32_t)__builtin_amdgcn_ds_bpermute(lo_addr, (int)P);
-        return ph - (lo_zero ? 0u : pl);
+    // horizontal window sums of the lane's CPL per-column values: the prefix over the tile's columns is a local
+    // prefix plus the wave scan of the lane totals; the window sum of column t is Q(t+W2) - Q(t-W2-1), both held
+    // by a neighbouring lane in a register known at compile time
+    auto horizontal = [&](uint32_t (&v)[CPL]) {
+#pragma unroll
+        for (int j = 1; j < CPL; j++) v[j] += v[j - 1];
+        const uint32_t excl = wave_scan(v[CPL - 1]) - v[CPL - 1];
+#pragma unroll
+        for (int j = 0; j < CPL; j++) v[j] += excl;
+        uint32_t out[CPL];
+#pragma unroll
+        for (int j = 0; j < CPL; j++) {
+            constexpr int dummy = 0; (void)dummy;
+            const int th = j + W2, tl = j - W2 - 1;                       // column offsets relative to the lane's first
+            const int lh = floordiv(th, CPL), jh = th - lh * CPL, ll = floordiv(tl, CPL), jl = tl - ll * CPL;
+            const uint32_t qh = (uint32_t)__builtin_amdgcn_ds_bpermute((lane + lh) * 4, (int)v[jh]);
+            const uint32_t ql = (uint32_t)__builtin_amdgcn_ds_bpermute((lane + ll) * 4, (int)v[jl]);
+            out[j] = qh - ((lane * CPL + tl < 0) ? 0u : ql);
+        }
+#pragma unroll
+        for (int j = 0; j < CPL; j++) v[j] = out[j];
     };
 
     // texture of the window: sum of |L - cap| (only needed with a texture threshold)
-    uint32_t tex[4] = {INF, INF, INF, INF};
+    uint32_t tex[4][CPL];
+#pragma unroll
+    for (int r = 0; r < 4; r++)
+#pragma unroll
+        for (int j = 0; j < CPL; j++) tex[r][j] = INF;
     if (a.texthr > 0) {
-        uint32_t Rd[NG], V[4];
+        uint32_t Rd[NG][CPL], V[CPL][4];
         const uint32_t ft = (uint32_t)(a.cap + 1) * 0x01010101u;
 #pragma unroll
-        for (int gi = 0; gi < NG; gi++) Rd[gi] = ft;
-        vertical(Rd, V);
+        for (int gi = 0; gi < NG; gi++)
 #pragma unroll
-        for (int r = 0; r < 4; r++) tex[r] = horizontal(V[r]);
-    }
-
-    uint32_t best[4], bk[4], pAt[4], nAt[4], prev[4];
-    uint32_t lmin[4], rmin[4], pm1[4], pm2[4];
+            for (int j = 0; j < CPL; j++) Rd[gi][j] = ft;
 #pragma unroll
-    for (int r = 0; r < 4; r++) {
-        best[r] = INF; bk[r] = 0x40000000u; pAt[r] = INF; nAt[r] = INF; prev[r] = INF;
-        lmin[r] = INF; rmin[r] = INF; pm1[r] = INF; pm2[r] = INF;
-    }
-    auto track = [&](int r, uint32_t k, uint32_t s) {
-        const bool above = bk[r] + 1 == k;                 // k is one above the current winner
-        if (above) nAt[r] = s;
-        const bool upd = s <= best[r];                      // ties go to the larger disparity
-        if (UNIQ) {
-            if (!upd && !above) rmin[r] = min(rmin[r], s);
-            if (upd) { lmin[r] = pm2[r]; rmin[r] = INF; }
-            pm2[r] = pm1[r]; pm1[r] = min(pm1[r], s);
-        }
-        if (upd) { pAt[r] = prev[r]; best[r] = s; bk[r] = k; }
-        prev[r] = s;
-    };
-
-    const int xbase = c - a.mindisp;
-    for (int k = 0; k < a.ndisp; k += 2) {
-        uint32_t R0[NG], R1[NG], V0[4], V1[4];
-        const int x0 = min(max(xbase - k, 0), W - 1), x1 = min(max(xbase - k - 1, 0), W - 1);
-#pragma unroll
-        for (int gi = 0; gi < NG; gi++) { R0[gi] = Rt[(size_t)gi * W + x0]; R1[gi] = Rt[(size_t)gi * W + x1]; }
-        vertical(R0, V0);
-        vertical(R1, V1);
+        for (int j = 0; j < CPL; j++) vertical(Rd, j, V[j]);
 #pragma unroll
         for (int r = 0; r < 4; r++) {
-            const uint32_t Hs = horizontal(V0[r] + (V1[r] << 16));   // exact: both halves stay below 2^16
-            track(r, (uint32_t)k, Hs & 0xFFFFu);
-            track(r, (uint32_t)k + 1u, Hs >> 16);
+            uint32_t h[CPL];
+#pragma unroll
+            for (int j = 0; j < CPL; j++) h[j] = V[j][r];
+            horizontal(h);
+#pragma unroll
+            for (int j = 0; j < CPL; j++) tex[r][j] = h[j];
         }
     }
 
-    const bool lane_ok = lane >= W2 && lane < 64 - W2 && c < a.xe;
+    // winner, its disparity + 1, the costs one below / one above it, the previous cost; for the uniqueness test
+    // the smallest cost at least two below (lmin) / two above (rmin) the winner and the delayed prefix minima
+    uint32_t best[4][CPL], bk1[4][CPL], pAt[4][CPL], nAt[4][CPL], prev[4][CPL];
+    uint32_t lmin[4][CPL], rmin[4][CPL], pm1[4][CPL], pm2[4][CPL];
+#pragma unroll
+    for (int r = 0; r < 4; r++)
+#pragma unroll
+        for (int j = 0; j < CPL; j++) {
+            best[r][j] = INF; bk1[r][j] = 0x40000000u; pAt[r][j] = INF; nAt[r][j] = INF; prev[r][j] = INF;
+            lmin[r][j] = INF; rmin[r][j] = INF; pm1[r][j] = INF; pm2[r][j] = INF;
+        }
+    auto track = [&](int r, int j, uint32_t k, uint32_t s) {
+        const bool above = bk1[r][j] == k;                  // k is one above the current winner
+        if (above) nAt[r][j] = s;
+        const bool upd = s <= best[r][j];                   // ties go to the larger disparity
+        if (UNIQ) {
+            if (!upd && !above) rmin[r][j] = min(rmin[r][j], s);
+            if (upd) { lmin[r][j] = pm2[r][j]; rmin[r][j] = INF; }
+            pm2[r][j] = pm1[r][j]; pm1[r][j] = min(pm1[r][j], s);
+        }
+        if (upd) { pAt[r][j] = prev[r][j]; bk1[r][j] = k + 1u; }
+        best[r][j] = min(best[r][j], s);
+        prev[r][j] = s;
+    };
+
+    const int xbase = c - a.mindisp;                         // R column of disparity index 0; xbase - k >= 0 for matched columns
+    auto rcol = [&](int k) { return min(max(xbase - k, 0), Wp - CPL); };
+    uint32_t R0[NG][CPL], R1[NG][CPL];
+    {
+        const int x0 = rcol(0), x1 = rcol(1);
+#pragma unroll
+        for (int gi = 0; gi < NG; gi++) { load4(Rt + (size_t)gi * Wp, x0, R0[gi]); load4(Rt + (size_t)gi * Wp, x1, R1[gi]); }
+    }
+    for (int k = 0; k < a.ndisp; k += 2) {
+        uint32_t P[4][CPL];
+#pragma unroll
+        for (int j = 0; j < CPL; j++) {
+            uint32_t V0[4], V1[4];
+            vertical(R0, j, V0);
+            vertical(R1, j, V1);
+#pragma unroll
+            for (int r = 0; r < 4; r++) P[r][j] = V0[r] + (V1[r] << 16);   // exact: both halves stay below 2^16
+        }
+        // the next two disparities' columns are fetched while this pair is reduced (the last fetch is unused)
+        {
+            const int x0 = rcol(k + 2), x1 = rcol(k + 3);
+#pragma unroll
+            for (int gi = 0; gi < NG; gi++) { load4(Rt + (size_t)gi * Wp, x0, R0[gi]); load4(Rt + (size_t)gi * Wp, x1, R1[gi]); }
+        }
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            horizontal(P[r]);
+#pragma unroll
+            for (int j = 0; j < CPL; j++) {
+                track(r, j, (uint32_t)k, P[r][j] & 0xFFFFu);
+                track(r, j, (uint32_t)k + 1u, P[r][j] >> 16);
+            }
+        }
+    }
+
     const int16_t filtered = (int16_t)((a.mindisp - 1) * 16);
 #pragma unroll
     for (int r = 0; r < 4; r++) {
         const int y = 4 * g + r;
-        if (y >= a.H || !lane_ok) continue;
-        const int kb = (int)bk[r], sb = (int)best[r];
-        const int pv = (int)(kb > 0 ? pAt[r] : nAt[r]);
-        const int nv = (int)(kb < a.ndisp - 1 ? nAt[r] : pAt[r]);
-        const int dd = pv + nv - 2 * sb + abs(pv - nv);
-        int16_t out = (int16_t)(((kb + a.mindisp) * 256 + (dd != 0 ? (pv - nv) * 256 / dd : 0) + 15) >> 4);
-        if ((int)tex[r] < a.texthr) out = filtered;
-        if (UNIQ) {
-            const int thresh = sb + sb * a.uniq / 100;
-            if ((int)min(lmin[r], rmin[r]) <= thresh) out = filtered;
+        if (y >= a.H) continue;
+        int16_t* drow = reinterpret_cast<int16_t*>(reinterpret_cast<char*>(a.disp) + (ptrdiff_t)blockIdx.z * a.dpair + (ptrdiff_t)y * a.dstride);
+#pragma unroll
+        for (int j = 0; j < CPL; j++) {
+            const int t = lane * CPL + j;
+            if (t < W2 || t >= TILE - W2 || c + j >= a.xe) continue;
+            const int kb = (int)bk1[r][j] - 1, sb = (int)best[r][j];
+            const int pv = (int)(kb > 0 ? pAt[r][j] : nAt[r][j]);
+            const int nv = (int)(kb < a.ndisp - 1 ? nAt[r][j] : pAt[r][j]);
+            const int dd = pv + nv - 2 * sb + abs(pv - nv);
+            int16_t out = (int16_t)(((kb + a.mindisp) * 256 + (dd != 0 ? (pv - nv) * 256 / dd : 0) + 15) >> 4);
+            if ((int)tex[r][j] < a.texthr) out = filtered;
+            if (UNIQ) {
+                const int thresh = sb + sb * a.uniq / 100;
+                if ((int)min(lmin[r][j], rmin[r][j]) <= thresh) out = filtered;
+            }
+            drow[c + j] = out;
         }
-        *reinterpret_cast<int16_t*>(reinterpret_cast<char*>(a.disp) + (ptrdiff_t)blockIdx.z * a.dpair + (ptrdiff_t)y * a.dstride + (ptrdiff_t)c * 2) = out;
     }
 }
 
@@ -240,7 +304,7 @@ __global__ void __launch_bounds__(256) bm_border_kernel(MatchArgs a)
 template <bool UNIQ>
 hipError_t launch_match(const MatchArgs& a, int w2, dim3 block, int n, hipStream_t st)
 {
-    const int tout = 64 - 2 * w2;
+    const int tout = TILE - 2 * w2;
     dim3 grid((a.xe - a.xs + tout - 1) / tout, (a.HG + 3) / 4, n);
     switch (w2) {
 #define ADF_BM_CASE(K) case K: hipLaunchKernelGGL((bm_match_kernel<K, UNIQ>), grid, block, 0, st, a); break;
@@ -357,14 +421,15 @@ extern "C" int adf_bm_compute_device(adf_bm_t* h, int n_pairs,
     DevScope ds(h->device);
     hipStream_t st = (hipStream_t)stream;
     const int HG = (H + 3) / 4, HGP = HG + 2 * PG;
-    const size_t view = (size_t)HGP * W;                       // dwords per prefiltered view
+    const int Wp = (W + XPAD + 3) / 4 * 4;                     // padded row: lanes past the image read (and discard) it
+    const size_t view = (size_t)HGP * Wp;                      // dwords per prefiltered view
     rc = reserve(&h->views, &h->views_bytes, 2 * view * (size_t)n_pairs * sizeof(uint32_t), st);
     if (rc) return rc;
     uint32_t* Lt = (uint32_t*)h->views;
     uint32_t* Rt = Lt + view * (size_t)n_pairs;
 
     PrefilterArgs p;
-    p.W = W; p.H = H; p.HGP = HGP; p.cap = h->cap; p.dst_pair = view;
+    p.W = W; p.Wp = Wp; p.H = H; p.HGP = HGP; p.cap = h->cap; p.dst_pair = view;
     dim3 pgrid((W + 255) / 256, HGP, n_pairs);
     p.src = left; p.stride = left_stride; p.pair_stride = left_pair_stride; p.dst = Lt;
     hipLaunchKernelGGL(bm_prefilter_kernel, pgrid, dim3(256), 0, st, p);
@@ -374,7 +439,7 @@ extern "C" int adf_bm_compute_device(adf_bm_t* h, int n_pairs,
     MatchArgs a;
     a.Lt = Lt; a.Rt = Rt; a.t_pair = view;
     a.disp = disparity; a.dstride = disp_stride; a.dpair = disp_pair_stride;
-    a.W = W; a.H = H; a.HG = HG;
+    a.W = W; a.Wp = Wp; a.H = H; a.HG = HG;
     a.mindisp = h->min_disp; a.ndisp = h->num_disp;
     const int w2 = h->block / 2, maxd = h->min_disp + h->num_disp - 1;
     a.xs = (maxd > 0 ? maxd : 0) + w2;
