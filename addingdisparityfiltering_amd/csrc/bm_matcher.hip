@@ -12,18 +12,19 @@
 // Layout.  The prefiltered views are stored "row-group interleaved": dword (g, x) holds the four
 // vertically adjacent pixels (x, 4g .. 4g+3) of column x, one byte each, as value+1 (so no byte is 0); PG
 // groups of replicated rows pad the top and the bottom.  One v_sad_u8 / v_msad_u8 then adds four rows of one
-// column of the SAD window, and a lane = one column reads consecutive dwords along a row of groups.
+// column of the SAD window, and a lane reads its four adjacent columns of a group as one 16-byte load.
 //
-// Kernel.  One wave = 64 adjacent columns (the outer W2 on each side are window halo) x one group of four
-// output rows; the four waves of a workgroup take four consecutive row groups.  Per disparity a lane forms
-// the four vertical window sums of its column (groups fully inside all four windows are summed once, the
-// partial ones through v_msad_u8 with the rows outside the window zeroed in the left operand), two
-// disparities are packed in one register (low / high half; a window sum is below 2^16), an inclusive wave
-// scan (DPP) and the difference of two permuted prefix values give the horizontal window sums, and the
-// winner with its two neighbours (and, for the uniqueness test, the smallest cost away from the winner) is
-// tracked in registers while the disparities stream by.  Nothing but the int16 result is written.
-// The kernel is VALU-bound (about 20 lane-operations per pixel and disparity), not HBM-bound: the views are
-// read through L1/L2 once per disparity, HBM sees them once.
+// Kernel.  One wave = 256 adjacent columns, four per lane (the outer W2 on each side are window halo) x one
+// group of four output rows; the four waves of a workgroup take four consecutive row groups.  Per disparity
+// and column a lane forms the four vertical window sums (groups fully inside all four windows are summed
+// once, the partial ones through v_msad_u8 with the rows outside the window zeroed in the left operand), two
+// disparities are packed in one register (low / high half; a window sum is below 2^16, and the prefix
+// arithmetic is exact modulo 2^32), a local prefix plus one DPP wave scan of the lane totals gives the prefix
+// over the tile's columns, the neighbours' prefix vectors come through a per-wave LDS slot, and the winner
+// with its two neighbours (and, for the uniqueness test, the smallest cost away from the winner) is tracked in
+// registers while the disparities stream by.  Nothing but the int16 result is written.
+// The kernel is bound by integer VALU issue (about 14 instructions per pixel and disparity), not
+// by HBM: the views are read through L1/L2 once per disparity, HBM sees them once.
 #include "adf_internal.h"
 #include "../../include/adf_wls.h"
 
@@ -105,7 +106,10 @@ __device__ __forceinline__ uint32_t wave_scan(uint32_t v)
     return v;
 }
 
-constexpr int CPL = 4;                 // adjacent columns per lane
+#ifndef ADF_BM_CPL
+#define ADF_BM_CPL 4
+#endif
+constexpr int CPL = ADF_BM_CPL;        // adjacent columns per lane
 constexpr int TILE = 64 * CPL;         // columns per wave, window halo included
 constexpr int XPAD = TILE + 4;         // columns of padding right of a prefiltered row (lanes past the image read it)
 constexpr int floordiv(int a, int b) { return (a >= 0) ? a / b : -((-a + b - 1) / b); }
@@ -127,10 +131,11 @@ __global__ void __launch_bounds__(256) bm_match_kernel(MatchArgs a)
     const uint32_t* __restrict__ Lt = a.Lt + voff;
     const uint32_t* __restrict__ Rt = a.Rt + voff;
 
-    auto load4 = [&](const uint32_t* row, int x, uint32_t (&d)[CPL]) {   // x .. x+3 are inside the padded row
-        struct __attribute__((aligned(4))) Quad { uint32_t v[4]; };      // dword-aligned 16-byte load
-        const Quad q = *reinterpret_cast<const Quad*>(row + x);
-        d[0] = q.v[0]; d[1] = q.v[1]; d[2] = q.v[2]; d[3] = q.v[3];
+    auto load4 = [&](const uint32_t* row, unsigned x, uint32_t (&d)[CPL]) {   // x .. x+3 are inside the padded row
+        struct __attribute__((aligned(4))) Vec { uint32_t v[CPL]; };     // one dword-aligned vector load
+        const Vec q = *reinterpret_cast<const Vec*>(row + x);
+#pragma unroll
+        for (int j = 0; j < CPL; j++) d[j] = q.v[j];
     };
     const int cl = min(c, Wp - CPL);
     uint32_t Ld[NG][CPL];
@@ -158,25 +163,34 @@ __global__ void __launch_bounds__(256) bm_match_kernel(MatchArgs a)
     };
     // horizontal window sums of the lane's CPL per-column values: the prefix over the tile's columns is a local
     // prefix plus the wave scan of the lane totals; the window sum of column t is Q(t+W2) - Q(t-W2-1), both held
-    // by a neighbouring lane in a register known at compile time
-    auto horizontal = [&](uint32_t (&v)[CPL]) {
+    // by a neighbouring lane in a register known at compile time.  The neighbours' prefixes travel through a
+    // per-wave LDS slot as whole vectors (one ds_write_b128, one ds_read_b128 per lane offset): ds_bpermute_b32
+    // costs the LDS pipe about 6 cycles per wave and dword, three times the vector path.
+    struct __attribute__((aligned(16))) Vec { uint32_t v[CPL]; };
+    __shared__ Vec xch[4][4][64];                            // [wave][output row][lane]
+    constexpr int LH0 = floordiv(W2, CPL), LH1 = floordiv(CPL - 1 + W2, CPL);          // lanes holding Q(t+W2)
+    constexpr int LL0 = floordiv(-W2 - 1, CPL), LL1 = floordiv(CPL - 2 - W2, CPL);     // lanes holding Q(t-W2-1)
+    const int iH0 = min(lane + LH0, 63), iH1 = min(lane + LH1, 63), iL0 = max(lane + LL0, 0), iL1 = max(lane + LL1, 0);
+    auto horizontal = [&](uint32_t (&v)[CPL], int r) {
 #pragma unroll
         for (int j = 1; j < CPL; j++) v[j] += v[j - 1];
         const uint32_t excl = wave_scan(v[CPL - 1]) - v[CPL - 1];
+        Vec q;
 #pragma unroll
-        for (int j = 0; j < CPL; j++) v[j] += excl;
-        uint32_t out[CPL];
+        for (int j = 0; j < CPL; j++) q.v[j] = v[j] + excl;
+        Vec* slot = xch[wave][r];
+        slot[lane] = q;
+        __builtin_amdgcn_wave_barrier();                      // same wave: the LDS queue is in order
+        const Vec hA = slot[iH0], hB = (LH1 != LH0) ? slot[iH1] : hA;
+        const Vec lA = slot[iL0], lB = (LL1 != LL0) ? slot[iL1] : lA;
 #pragma unroll
         for (int j = 0; j < CPL; j++) {
-            constexpr int dummy = 0; (void)dummy;
             const int th = j + W2, tl = j - W2 - 1;                       // column offsets relative to the lane's first
             const int lh = floordiv(th, CPL), jh = th - lh * CPL, ll = floordiv(tl, CPL), jl = tl - ll * CPL;
-            const uint32_t qh = (uint32_t)__builtin_amdgcn_ds_bpermute((lane + lh) * 4, (int)v[jh]);
-            const uint32_t ql = (uint32_t)__builtin_amdgcn_ds_bpermute((lane + ll) * 4, (int)v[jl]);
-            out[j] = qh - ((lane * CPL + tl < 0) ? 0u : ql);
+            const uint32_t qh = (lh == LH0) ? hA.v[jh] : hB.v[jh];
+            const uint32_t ql = (ll == LL0) ? lA.v[jl] : lB.v[jl];
+            v[j] = qh - ((lane * CPL + tl < 0) ? 0u : ql);
         }
-#pragma unroll
-        for (int j = 0; j < CPL; j++) v[j] = out[j];
     };
 
     // texture of the window: sum of |L - cap| (only needed with a texture threshold)
@@ -199,7 +213,7 @@ __global__ void __launch_bounds__(256) bm_match_kernel(MatchArgs a)
             uint32_t h[CPL];
 #pragma unroll
             for (int j = 0; j < CPL; j++) h[j] = V[j][r];
-            horizontal(h);
+            horizontal(h, r);
 #pragma unroll
             for (int j = 0; j < CPL; j++) tex[r][j] = h[j];
         }
@@ -216,8 +230,15 @@ __global__ void __launch_bounds__(256) bm_match_kernel(MatchArgs a)
             best[r][j] = INF; bk1[r][j] = 0x40000000u; pAt[r][j] = INF; nAt[r][j] = INF; prev[r][j] = INF;
             lmin[r][j] = INF; rmin[r][j] = INF; pm1[r][j] = INF; pm2[r][j] = INF;
         }
+    // `after`: the previous disparity became the winner, so this cost is the one above it (the flag is the
+    // previous step's compare result, carried in scalar registers)
+    bool after[4][CPL];
+#pragma unroll
+    for (int r = 0; r < 4; r++)
+#pragma unroll
+        for (int j = 0; j < CPL; j++) after[r][j] = false;
     auto track = [&](int r, int j, uint32_t k, uint32_t s) {
-        const bool above = bk1[r][j] == k;                  // k is one above the current winner
+        const bool above = after[r][j];
         if (above) nAt[r][j] = s;
         const bool upd = s <= best[r][j];                   // ties go to the larger disparity
         if (UNIQ) {
@@ -228,15 +249,16 @@ __global__ void __launch_bounds__(256) bm_match_kernel(MatchArgs a)
         if (upd) { pAt[r][j] = prev[r][j]; bk1[r][j] = k + 1u; }
         best[r][j] = min(best[r][j], s);
         prev[r][j] = s;
+        after[r][j] = upd;
     };
 
     const int xbase = c - a.mindisp;                         // R column of disparity index 0; xbase - k >= 0 for matched columns
-    auto rcol = [&](int k) { return min(max(xbase - k, 0), Wp - CPL); };
+    auto rcol = [&](int k) -> unsigned { return (unsigned)min(max(xbase - k, 0), Wp - CPL); };
     uint32_t R0[NG][CPL], R1[NG][CPL];
     {
-        const int x0 = rcol(0), x1 = rcol(1);
+        const unsigned x0 = rcol(0), x1 = rcol(1);
 #pragma unroll
-        for (int gi = 0; gi < NG; gi++) { load4(Rt + (size_t)gi * Wp, x0, R0[gi]); load4(Rt + (size_t)gi * Wp, x1, R1[gi]); }
+        for (int gi = 0; gi < NG; gi++) { load4(Rt + (size_t)gi * (unsigned)Wp, x0, R0[gi]); load4(Rt + (size_t)gi * (unsigned)Wp, x1, R1[gi]); }
     }
     for (int k = 0; k < a.ndisp; k += 2) {
         uint32_t P[4][CPL];
@@ -250,13 +272,13 @@ __global__ void __launch_bounds__(256) bm_match_kernel(MatchArgs a)
         }
         // the next two disparities' columns are fetched while this pair is reduced (the last fetch is unused)
         {
-            const int x0 = rcol(k + 2), x1 = rcol(k + 3);
+            const unsigned x0 = rcol(k + 2), x1 = rcol(k + 3);
 #pragma unroll
-            for (int gi = 0; gi < NG; gi++) { load4(Rt + (size_t)gi * Wp, x0, R0[gi]); load4(Rt + (size_t)gi * Wp, x1, R1[gi]); }
+            for (int gi = 0; gi < NG; gi++) { load4(Rt + (size_t)gi * (unsigned)Wp, x0, R0[gi]); load4(Rt + (size_t)gi * (unsigned)Wp, x1, R1[gi]); }
         }
 #pragma unroll
         for (int r = 0; r < 4; r++) {
-            horizontal(P[r]);
+            horizontal(P[r], r);
 #pragma unroll
             for (int j = 0; j < CPL; j++) {
                 track(r, j, (uint32_t)k, P[r][j] & 0xFFFFu);
