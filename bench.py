@@ -43,6 +43,8 @@ def parse_args():
                          "the results over RCCL point-to-point groups (outside the timed region either way)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU baseline budget (0 = skip)")
     ap.add_argument("--no-check", action="store_true", help="skip the oracle check of pair 0")
+    ap.add_argument("--matcher-pairs", type=int, default=4,
+                    help="pairs of the extra views -> matcher -> filter leg (SURVEY 8f N4; N=1 only, 0 = skip)")
     return ap.parse_args()
 
 
@@ -80,6 +82,33 @@ def cpu_baseline(view, dl, dr, roi, radius, seconds):
                   "(scalar order, pthread stripes); %d logical CPUs visible; tried %s"
                   % (n, W, H, avail, "; ".join(tried)),
     }
+
+
+def views_to_filtered(xi, view, roi, radius, n, num_disp, block):
+    """Extra leg, outside the timed region and not part of `value`: the device block matcher (both views) feeding the
+    filter, all stages on torch's stream, inputs resident."""
+    import torch
+    left = view[:n, :, :, 0].contiguous()
+    right = torch.roll(left, -min(num_disp // 3, 60), 2).contiguous()
+    lm = xi.StereoBM.create(num_disp, block)
+    wls = xi.createDisparityWLSFilter(lm)                    # DF.cpp:386-414 (forces texture / uniqueness tests off)
+    rm = xi.createRightMatcher(lm)                           # DF.cpp:417-431
+    wls.setLambda(8000.0); wls.setSigmaColor(1.5)
+    H, W = left.shape[1:]
+    dl = torch.empty((n, H, W), dtype=torch.int16, device=left.device); dr = torch.empty_like(dl); out = torch.empty_like(dl)
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+    for it in range(2):                                      # first round warms the workspaces up
+        ev[0].record()
+        lm.compute(left, right, dl); rm.compute(right, left, dr)
+        ev[1].record()
+        wls.filter(dl, view[:n], out, dr)
+        ev[2].record()
+    torch.cuda.synchronize()
+    return {"pairs": n, "num_disparities": num_disp, "block_size": block, "roi": list(wls.getROI()),
+            "matcher_ms_per_pair": round(ev[0].elapsed_time(ev[1]) / n, 4),
+            "filter_ms_per_pair": round(ev[1].elapsed_time(ev[2]) / n, 4),
+            "Mpixels_per_s": round(n * H * W / (ev[0].elapsed_time(ev[2]) * 1e-3) / 1e6, 1),
+            "note": "block matcher (left + right view) then filter, one call each for the batch; not part of `value`"}
 
 
 def main():
@@ -265,6 +294,14 @@ def main():
         cpu = cpu_baseline(view[:ncpu].cpu().numpy(), dl[:ncpu].cpu().numpy(), dr[:ncpu].cpu().numpy(), roi, radius,
                            args.cpu_seconds)
 
+    pipeline = None
+    if world == 1 and args.matcher_pairs > 0:
+        try:
+            nd = max(16, (roi[0] + 15) // 16 * 16)           # the config's ROI x is its numDisparities
+            pipeline = views_to_filtered(adf, view, roi, radius, min(args.matcher_pairs, pairs), min(nd, 256), 15)
+        except Exception as e:                               # the extra leg must never cost the bench line
+            pipeline = {"error": str(e)}
+
     F = W * H
     b_alg_pair = 10.0 * F + (ch + 8 + 120) * P  # I/O + weights + 6 passes
     line = {
@@ -283,6 +320,7 @@ def main():
         "scatter_ms": None if scatter_ms is None else round(scatter_ms, 2),
         "gather_ms": None if gather_ms is None else round(gather_ms, 2),
         "workspace_GB": round(f.workspaceBytes() / 1e9, 2),
+        "views_to_filtered": pipeline,
     }
     if cpu:
         line["speedup_vs_cpu"] = round(mpx / cpu["value"], 1)

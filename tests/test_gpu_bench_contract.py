@@ -33,3 +33,6 @@ def test_bench_line_contract():
         assert key in c, key
     assert c["kind"] in ("port", "reference") and c["value"] > 0 and c["cores"] >= 1
     assert d["checked"]["confidence_bit_exact"] is True and d["checked"]["disparity_max_abs_lsb"] <= 1
+    v = d["views_to_filtered"]                       # extra leg: device matcher feeding the filter
+    assert "error" not in v, v
+    assert v["matcher_ms_per_pair"] > 0 and v["filter_ms_per_pair"] > 0 and v["num_disparities"] % 16 == 0
