@@ -167,17 +167,25 @@ __global__ void __launch_bounds__(256) bm_match_kernel(MatchArgs a)
     // per-wave LDS slot as whole vectors (one ds_write_b128, one ds_read_b128 per lane offset): ds_bpermute_b32
     // costs the LDS pipe about 6 cycles per wave and dword, three times the vector path.
     struct __attribute__((aligned(16))) Vec { uint32_t v[CPL]; };
-    __shared__ Vec xch[4][4][64];                            // [wave][output row][lane]
+    __shared__ Vec xch[4][4][65];                            // [wave][output row][lane]; entry 64 stays zero = Q(-1)
     constexpr int LH0 = floordiv(W2, CPL), LH1 = floordiv(CPL - 1 + W2, CPL);          // lanes holding Q(t+W2)
     constexpr int LL0 = floordiv(-W2 - 1, CPL), LL1 = floordiv(CPL - 2 - W2, CPL);     // lanes holding Q(t-W2-1)
-    const int iH0 = min(lane + LH0, 63), iH1 = min(lane + LH1, 63), iL0 = max(lane + LL0, 0), iL1 = max(lane + LL1, 0);
+    const int iH0 = min(lane + LH0, 63), iH1 = min(lane + LH1, 63);
+    const int iL0 = lane + LL0 < 0 ? 64 : lane + LL0, iL1 = lane + LL1 < 0 ? 64 : lane + LL1;   // a lane left of the tile: all its columns are
+    if (lane < 4) {
+        Vec z;
+#pragma unroll
+        for (int j = 0; j < CPL; j++) z.v[j] = 0;
+        xch[wave][lane][64] = z;
+    }
     auto horizontal = [&](uint32_t (&v)[CPL], int r) {
+        uint32_t tot = v[0];
 #pragma unroll
-        for (int j = 1; j < CPL; j++) v[j] += v[j - 1];
-        const uint32_t excl = wave_scan(v[CPL - 1]) - v[CPL - 1];
-        Vec q;
+        for (int j = 1; j < CPL; j++) tot += v[j];
+        Vec q;                                                // inclusive prefix: the scan result is the last column's
+        q.v[CPL - 1] = wave_scan(tot);
 #pragma unroll
-        for (int j = 0; j < CPL; j++) q.v[j] = v[j] + excl;
+        for (int j = CPL - 2; j >= 0; j--) q.v[j] = q.v[j + 1] - v[j + 1];
         Vec* slot = xch[wave][r];
         slot[lane] = q;
         __builtin_amdgcn_wave_barrier();                      // same wave: the LDS queue is in order
@@ -189,7 +197,7 @@ __global__ void __launch_bounds__(256) bm_match_kernel(MatchArgs a)
             const int lh = floordiv(th, CPL), jh = th - lh * CPL, ll = floordiv(tl, CPL), jl = tl - ll * CPL;
             const uint32_t qh = (lh == LH0) ? hA.v[jh] : hB.v[jh];
             const uint32_t ql = (ll == LL0) ? lA.v[jl] : lB.v[jl];
-            v[j] = qh - ((lane * CPL + tl < 0) ? 0u : ql);
+            v[j] = qh - ql;
         }
     };
 
@@ -241,15 +249,30 @@ __global__ void __launch_bounds__(256) bm_match_kernel(MatchArgs a)
         const bool above = after[r][j];
         if (above) nAt[r][j] = s;
         const bool upd = s <= best[r][j];                   // ties go to the larger disparity
-        if (UNIQ) {
-            if (!upd && !above) rmin[r][j] = min(rmin[r][j], s);
-            if (upd) { lmin[r][j] = pm2[r][j]; rmin[r][j] = INF; }
-            pm2[r][j] = pm1[r][j]; pm1[r][j] = min(pm1[r][j], s);
-        }
+        if (!upd && !above) rmin[r][j] = min(rmin[r][j], s);
+        if (upd) { lmin[r][j] = pm2[r][j]; rmin[r][j] = INF; }
+        pm2[r][j] = pm1[r][j]; pm1[r][j] = min(pm1[r][j], s);
         if (upd) { pAt[r][j] = prev[r][j]; bk1[r][j] = k + 1u; }
         best[r][j] = min(best[r][j], s);
         prev[r][j] = s;
         after[r][j] = upd;
+    };
+    // Without the uniqueness test only the winner and its two neighbours matter, and the neighbours are captured
+    // as whole packed registers (pAt / nAt hold the pair register that contains the neighbour; which half is
+    // decided at the end from the winner's parity): no unpacked copy of a cost is ever stored.
+    //   winner at even k (low half of P):  below = high half of the previous pair, above = high half of P
+    //   winner at odd k  (high half of P): below = low half of P,                 above = low half of the next pair
+    auto track_pair = [&](int r, int j, uint32_t k, uint32_t Pk) {
+        const uint32_t lo = Pk & 0xFFFFu, hi = Pk >> 16;
+        const bool updE = lo <= best[r][j];
+        best[r][j] = min(best[r][j], lo);
+        const bool updO = hi <= best[r][j];
+        best[r][j] = min(best[r][j], hi);
+        if (after[r][j] || updE) nAt[r][j] = Pk;
+        if (updE) { pAt[r][j] = prev[r][j]; bk1[r][j] = k + 1u; }
+        if (updO) { pAt[r][j] = Pk; bk1[r][j] = k + 2u; }
+        after[r][j] = updO;
+        prev[r][j] = Pk;
     };
 
     const int xbase = c - a.mindisp;                         // R column of disparity index 0; xbase - k >= 0 for matched columns
@@ -281,8 +304,12 @@ __global__ void __launch_bounds__(256) bm_match_kernel(MatchArgs a)
             horizontal(P[r], r);
 #pragma unroll
             for (int j = 0; j < CPL; j++) {
-                track(r, j, (uint32_t)k, P[r][j] & 0xFFFFu);
-                track(r, j, (uint32_t)k + 1u, P[r][j] >> 16);
+                if (UNIQ) {
+                    track(r, j, (uint32_t)k, P[r][j] & 0xFFFFu);
+                    track(r, j, (uint32_t)k + 1u, P[r][j] >> 16);
+                } else {
+                    track_pair(r, j, (uint32_t)k, P[r][j]);
+                }
             }
         }
     }
@@ -298,8 +325,13 @@ __global__ void __launch_bounds__(256) bm_match_kernel(MatchArgs a)
             const int t = lane * CPL + j;
             if (t < W2 || t >= TILE - W2 || c + j >= a.xe) continue;
             const int kb = (int)bk1[r][j] - 1, sb = (int)best[r][j];
-            const int pv = (int)(kb > 0 ? pAt[r][j] : nAt[r][j]);
-            const int nv = (int)(kb < a.ndisp - 1 ? nAt[r][j] : pAt[r][j]);
+            uint32_t below = pAt[r][j], above = nAt[r][j];
+            if (!UNIQ) {                                                   // packed captures: pick the half
+                below = (kb & 1) ? (below & 0xFFFFu) : (below >> 16);
+                above = (kb & 1) ? (above & 0xFFFFu) : (above >> 16);
+            }
+            const int pv = (int)(kb > 0 ? below : above);
+            const int nv = (int)(kb < a.ndisp - 1 ? above : below);
             const int dd = pv + nv - 2 * sb + abs(pv - nv);
             int16_t out = (int16_t)(((kb + a.mindisp) * 256 + (dd != 0 ? (pv - nv) * 256 / dd : 0) + 15) >> 4);
             if ((int)tex[r][j] < a.texthr) out = filtered;
