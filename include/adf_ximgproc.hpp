@@ -241,6 +241,77 @@ inline cv::Ptr<cv::StereoMatcher> createRightMatcher(cv::Ptr<cv::StereoMatcher> 
 }
 #endif
 
+// ---------------------------------------------------------------------------------------------------------
+// Block matcher feeding the filter.  cv::StereoBM is a class of OpenCV's calib3d, outside the
+// reference tree (parity unpinned there); this class carries its accessor names over adf_bm_* so that the
+// sample's pipeline (samples/disparity_filtering.cpp:151-189) reads the same.  Host images in, host image out;
+// device-resident pipelines call adf_bm_compute_device directly.
+// ---------------------------------------------------------------------------------------------------------
+class StereoBM {
+    adf_bm_t* h_ = nullptr;
+    int min_disp_ = 0, num_disp_, block_, cap_ = 31, texture_ = 10, uniq_ = 15;   // cv::StereoBM's defaults
+    int disp12_ = -1, speckle_window_ = 0;
+public:
+    StereoBM(int numDisparities, int blockSize) : num_disp_(numDisparities > 0 ? numDisparities : 64), block_(blockSize)
+    {
+        check(adf_bm_create(&h_, num_disp_, block_));
+    }
+    ~StereoBM() { adf_bm_destroy(h_); }
+    StereoBM(const StereoBM&) = delete;
+    StereoBM& operator=(const StereoBM&) = delete;
+    static Ptr<StereoBM> create(int numDisparities = 0, int blockSize = 21) { return Ptr<StereoBM>(new StereoBM(numDisparities, blockSize)); }
+    int getMinDisparity() const { return min_disp_; }        void setMinDisparity(int v) { min_disp_ = v; }
+    int getNumDisparities() const { return num_disp_; }      void setNumDisparities(int v) { num_disp_ = v; }
+    int getBlockSize() const { return block_; }              void setBlockSize(int v) { block_ = v; }
+    int getPreFilterCap() const { return cap_; }             void setPreFilterCap(int v) { cap_ = v; }
+    int getTextureThreshold() const { return texture_; }     void setTextureThreshold(int v) { texture_ = v; }
+    int getUniquenessRatio() const { return uniq_; }         void setUniquenessRatio(int v) { uniq_ = v; }
+    int getDisp12MaxDiff() const { return disp12_; }         void setDisp12MaxDiff(int v) { disp12_ = v; }
+    int getSpeckleWindowSize() const { return speckle_window_; } void setSpeckleWindowSize(int v) { speckle_window_ = v; }
+    // StereoMatcher::compute: CV_8UC1 views -> CV_16SC1 disparity * 16, rejected pixels (minDisparity - 1) * 16
+    void compute(const Mat& left, const Mat& right, Mat& disparity)
+    {
+        if (left.empty() || right.empty() || mat_depth(left) != D8U || mat_depth(right) != D8U ||
+            mat_channels(left) != 1 || mat_channels(right) != 1)
+            throw Exception(ADF_EBADARG, "Both input images must have CV_8UC1");
+        if (left.rows != right.rows || left.cols != right.cols)
+            throw Exception(ADF_ESIZE, "All the images must have the same size");
+        if ((disp12_ >= 0 && disp12_ < 1000000) || speckle_window_ > 0)          // the filter factory switches both off (DF.cpp:389-390)
+            throw Exception(ADF_EBADARG, "the matcher's own left-right check and speckle filter are not implemented");
+        check(adf_bm_set_params(h_, min_disp_, num_disp_, block_, cap_, texture_, uniq_));
+        Mat out;
+        mat_create(out, left.rows, left.cols, D16S, 1);
+        check(adf_bm_compute_host(h_, 1, left.data, mat_step(left), 0, right.data, mat_step(right), 0, left.cols, left.rows,
+                                  reinterpret_cast<int16_t*>(out.data), mat_step(out), 0));
+        disparity = out;
+    }
+};
+
+// DF.cpp:386-403 (StereoBM branch): mutates the matcher exactly like the reference, derives ROI offsets and radius
+inline Ptr<DisparityWLSFilter> createDisparityWLSFilter(const Ptr<StereoBM>& matcher_left)
+{
+    matcher_left->setDisp12MaxDiff(1000000);
+    matcher_left->setSpeckleWindowSize(0);
+    matcher_left->setTextureThreshold(0);
+    matcher_left->setUniquenessRatio(0);
+    return createDisparityWLSFilter(false, matcher_left->getMinDisparity(), matcher_left->getNumDisparities(),
+                                    matcher_left->getBlockSize());
+}
+
+// DF.cpp:417-431
+inline Ptr<StereoBM> createRightMatcher(const Ptr<StereoBM>& matcher_left)
+{
+    const int min_disp = matcher_left->getMinDisparity(), num_disp = matcher_left->getNumDisparities();
+    Ptr<StereoBM> right_bm = StereoBM::create(num_disp, matcher_left->getBlockSize());
+    right_bm->setMinDisparity(-(min_disp + num_disp) + 1);
+    right_bm->setTextureThreshold(0);
+    right_bm->setUniquenessRatio(0);
+    right_bm->setDisp12MaxDiff(1000000);
+    right_bm->setSpeckleWindowSize(0);
+    right_bm->setPreFilterCap(matcher_left->getPreFilterCap());
+    return right_bm;
+}
+
 // EF.hpp:361-371
 class FastGlobalSmootherFilter {
     adf_fgs_t* h_ = nullptr;

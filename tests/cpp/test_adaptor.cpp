@@ -90,6 +90,49 @@ int main()
         for (int i = 0; i < 600; i++) for (int j = 0; j < 700; j++) l1 += std::abs(res.ptr<int16_t>(i)[j] - 123);
         EXPECT(l1 / (600.0 * 700.0) <= 1.0 / 64);
     }
+    {   // views -> left / right block matcher -> filter (samples/disparity_filtering.cpp:151-189) against the oracle's pipeline
+        std::mt19937 rng(5);
+        const int W = 200, H = 96, nd = 32, wsz = 9;
+        Mat base(H, W + 64, D8U, 1), left(H, W, D8U, 1), right(H, W, D8U, 1);
+        for (int i = 0; i < H; i++) for (int j = 0; j < W + 64; j++) {
+            const int v = (int)(rng() % 256);
+            base.ptr<unsigned char>(i)[j] = (unsigned char)((j > 0 ? (base.ptr<unsigned char>(i)[j - 1] + v) / 2 : v));
+        }
+        for (int i = 0; i < H; i++) for (int j = 0; j < W; j++) {
+            left.ptr<unsigned char>(i)[j] = base.ptr<unsigned char>(i)[j + 20];
+            right.ptr<unsigned char>(i)[j] = base.ptr<unsigned char>(i)[j + 20 + (i < H / 2 ? 6 : 11)];   // two disparity layers
+        }
+        Ptr<StereoBM> lm = StereoBM::create(nd, wsz);
+        Ptr<DisparityWLSFilter> wls = createDisparityWLSFilter(lm);             // DF.cpp:386-403
+        Ptr<StereoBM> rm = createRightMatcher(lm);                              // DF.cpp:417-431
+        EXPECT(lm->getTextureThreshold() == 0 && lm->getUniquenessRatio() == 0 && rm->getMinDisparity() == -nd + 1);
+        wls->setLambda(8000.0); wls->setSigmaColor(1.5); wls->setSolver(ADF_SOLVER_EXACT);
+        Mat dl, dr, out;
+        lm->compute(left, right, dl);
+        rm->compute(right, left, dr);
+        wls->filter(dl, left, out, dr);
+        adf_oracle_bm_params bp = {0, nd, wsz, 31, 0, 0};
+        Mat edl(H, W, D16S, 1), edr(H, W, D16S, 1), exp(H, W, D16S, 1);
+        EXPECT(adf_oracle_bm_compute(&bp, left.data, (ptrdiff_t)left.step, right.data, (ptrdiff_t)right.step, W, H, edl.ptr<int16_t>(), W) == 0);
+        bp.min_disparity = -nd + 1;
+        EXPECT(adf_oracle_bm_compute(&bp, right.data, (ptrdiff_t)right.step, left.data, (ptrdiff_t)left.step, W, H, edr.ptr<int16_t>(), W) == 0);
+        EXPECT(std::memcmp(dl.data, edl.data, (size_t)H * edl.step) == 0);
+        EXPECT(std::memcmp(dr.data, edr.data, (size_t)H * edr.step) == 0);
+        long hits = 0;                                                        // the two layers are found
+        for (int i = 4; i < H / 2 - 4; i++) for (int j = 60; j < W - 10; j++) hits += std::labs(dl.ptr<int16_t>(i)[j] - 6 * 16) <= 8;
+        EXPECT(hits > (long)(H / 2 - 8) * (W - 70) * 9 / 10);
+        Rect r = wls->getROI();
+        EXPECT(r.x == nd + wsz / 2 && r.y == wsz / 2 && r.width == W - nd - 2 * (wsz / 2) && r.height == H - 2 * (wsz / 2));
+        adf_oracle_params p; adf_oracle_default_params(&p);
+        p.lambda = 8000.0; p.sigma_color = 1.5; p.use_confidence = 1; p.threads = 2; p.disc_radius = wls->getDepthDiscontinuityRadius();
+        EXPECT(adf_oracle_wls_filter(&p, edl.ptr<int16_t>(), (ptrdiff_t)edl.step, left.data, (ptrdiff_t)left.step, 1, W, H,
+                                     edr.ptr<int16_t>(), (ptrdiff_t)edr.step, r.x, r.y, r.width, r.height,
+                                     exp.ptr<int16_t>(), (ptrdiff_t)exp.step, nullptr) == 0);
+        EXPECT(std::memcmp(out.data, exp.data, (size_t)H * exp.step) == 0);
+        bool threw = false;
+        try { StereoBM::create(24, 9)->compute(left, right, dl); } catch (const Exception&) { threw = true; }   // not divisible by 16
+        EXPECT(threw);
+    }
     {   // error behaviour: exceptions like CV_Assert / CV_Error
         Mat view(48, 64, D8U, 3), dl(48, 64, D16S, 1), out;
         Ptr<DisparityWLSFilter> wls = createDisparityWLSFilterGeneric(true);
