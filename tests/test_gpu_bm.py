@@ -129,3 +129,19 @@ def test_views_to_filtered_disparity_on_device(adf, oracle):
     g = gt[y:y + h, x:x + w].astype(np.int64); known = g != 0
     mse = lambda d: (((g - d[y:y + h, x:x + w].astype(np.int64))[known]) ** 2).mean() / 256.0
     assert mse(out.cpu().numpy()) <= mse(edl)
+
+
+def test_random_parameters_bit_exact(adf, oracle):
+    """Seeded fuzz over sizes and every parameter of the matcher (the reference has no such test for a matcher:
+    this guards the kernel's template / tiling arithmetic)."""
+    rng = np.random.default_rng(2024)
+    for case in range(40):
+        wsz = int(rng.choice([5, 7, 9, 11, 13, 15, 17, 19, 21]))
+        nd = 16 * int(rng.integers(1, 7))
+        md = int(rng.integers(-nd - 10, 24))
+        H = int(rng.integers(wsz + 1, 70)); W = int(rng.integers(max(wsz + 1, 40), 560))
+        cap = int(rng.integers(1, 64)); texthr = int(rng.choice([0, 0, 10, 200])); uniq = int(rng.choice([0, 0, 5, 25]))
+        left, right = _views(1000 + case, H, W, shift=int(rng.integers(0, 12)))
+        got = _bm(adf, nd, wsz, md, cap, texthr, uniq).compute(left, right)
+        exp = oracle.bm_compute(left, right, nd, wsz, md, cap, texthr, uniq)
+        assert np.array_equal(got, exp), (case, H, W, nd, wsz, md, cap, texthr, uniq)
