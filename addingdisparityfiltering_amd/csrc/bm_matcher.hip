@@ -257,21 +257,25 @@ __global__ void __launch_bounds__(256) bm_match_kernel(MatchArgs a)
         prev[r][j] = s;
         after[r][j] = upd;
     };
-    // Without the uniqueness test only the winner and its two neighbours matter, and the neighbours are captured
-    // as whole packed registers (pAt / nAt hold the pair register that contains the neighbour; which half is
-    // decided at the end from the winner's parity): no unpacked copy of a cost is ever stored.
-    //   winner at even k (low half of P):  below = high half of the previous pair, above = high half of P
-    //   winner at odd k  (high half of P): below = low half of P,                 above = low half of the next pair
+    // Without the uniqueness test only the winner and its two neighbours matter, and all three are captured as
+    // whole pair registers: a pair (disparities k, k+1) is compared through its smaller half, and when it beats
+    // the winner the pair itself (capW), the pair before it (pAt) and -- one step later -- the pair after it (nAt)
+    // are kept.  Which half won (the high one on a tie: ties go to the larger disparity) and which halves are the
+    // neighbours is decided once, at the end:
+    //   winner in the low half  (even k): below = high half of the previous pair, above = high half of capW
+    //   winner in the high half (odd k):  below = low half of capW,              above = low half of the next pair
+    uint32_t capW[4][CPL];
+#pragma unroll
+    for (int r = 0; r < 4; r++)
+#pragma unroll
+        for (int j = 0; j < CPL; j++) capW[r][j] = 0;
     auto track_pair = [&](int r, int j, uint32_t k, uint32_t Pk) {
-        const uint32_t lo = Pk & 0xFFFFu, hi = Pk >> 16;
-        const bool updE = lo <= best[r][j];
-        best[r][j] = min(best[r][j], lo);
-        const bool updO = hi <= best[r][j];
-        best[r][j] = min(best[r][j], hi);
-        if (after[r][j] || updE) nAt[r][j] = Pk;
-        if (updE) { pAt[r][j] = prev[r][j]; bk1[r][j] = k + 1u; }
-        if (updO) { pAt[r][j] = Pk; bk1[r][j] = k + 2u; }
-        after[r][j] = updO;
+        const uint32_t m = min(Pk & 0xFFFFu, Pk >> 16);
+        const bool upd = m <= best[r][j];
+        best[r][j] = min(best[r][j], m);
+        if (after[r][j]) nAt[r][j] = Pk;
+        if (upd) { capW[r][j] = Pk; pAt[r][j] = prev[r][j]; bk1[r][j] = k + 1u; }
+        after[r][j] = upd;
         prev[r][j] = Pk;
     };
 
@@ -324,11 +328,15 @@ __global__ void __launch_bounds__(256) bm_match_kernel(MatchArgs a)
         for (int j = 0; j < CPL; j++) {
             const int t = lane * CPL + j;
             if (t < W2 || t >= TILE - W2 || c + j >= a.xe) continue;
-            const int kb = (int)bk1[r][j] - 1, sb = (int)best[r][j];
+            int kb = (int)bk1[r][j] - 1;
+            const int sb = (int)best[r][j];
             uint32_t below = pAt[r][j], above = nAt[r][j];
-            if (!UNIQ) {                                                   // packed captures: pick the half
-                below = (kb & 1) ? (below & 0xFFFFu) : (below >> 16);
-                above = (kb & 1) ? (above & 0xFFFFu) : (above >> 16);
+            if (!UNIQ) {                                                   // packed captures: kb is the pair's even disparity
+                const uint32_t wl = capW[r][j] & 0xFFFFu, wh = capW[r][j] >> 16;
+                const bool odd = wh <= wl;
+                below = odd ? wl : (below >> 16);
+                above = odd ? (above & 0xFFFFu) : wh;
+                kb += odd ? 1 : 0;
             }
             const int pv = (int)(kb > 0 ? below : above);
             const int nv = (int)(kb < a.ndisp - 1 ? above : below);
