@@ -242,3 +242,25 @@ def test_filter_call_is_graph_capturable(adf, oracle):
     d = np.abs(out.cpu().numpy().astype(np.int64) - exp)
     assert d.max() <= MAX_DIF and d.mean() <= MAX_MEAN_DIF
     assert not torch.equal(out, eager)
+
+
+def test_device_call_is_graph_capturable(adf):
+    """once the workspace exists the device entry point queues kernels only (the side
+    stream's fork / join included), so a call can be captured into a HIP graph and replayed."""
+    import torch
+    view, dl, dr, roi, radius = synthetic.make_config_example(5)
+    tv, tl, tr = (torch.from_numpy(a).cuda() for a in (view, dl, dr))
+    out = torch.empty_like(tl)
+    f = adf.createDisparityWLSFilterGeneric(True)
+    f.setLambda(8000.0); f.setSigmaColor(1.5); f.setDepthDiscontinuityRadius(radius)
+    f.filter(tl, tv, out, tr, roi)                      # sizes the workspace
+    torch.cuda.synchronize()
+    ref, ref_conf = out.clone(), f.getConfidenceMap().clone()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        f.filter(tl, tv, out, tr, roi)
+    for _ in range(3):
+        out.zero_()
+        g.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(out, ref) and torch.equal(f.getConfidenceMap(), ref_conf)
