@@ -4,6 +4,8 @@
   profiles/r01_<solver>_bench_kernel_stats.csv rocprofv3 --kernel-trace --stats (kernel_stats), our kernels first
   profiles/r01_<solver>_pmc_8pairs.csv         HBM bytes per launch from the FETCH_SIZE / WRITE_SIZE passes
   profiles/pmc_traffic.json                    bytes per stereo pair per kernel (bench.py's roofline.traffic)
+  profiles/r01_matcher_kernel_stats.csv        rocprofv3 --kernel-trace --stats of tools/bm_time.py (block matcher, N4)
+  profiles/r01_matcher_times.txt               its timings and the oracle's CPU time
 
 FETCH_SIZE / WRITE_SIZE are in KB; on gfx950 FETCH_SIZE reports half of a coalesced streaming read
 (MI355X_MICROARCH.md, HBM section), so reads are doubled.
@@ -66,6 +68,14 @@ def main(solver):
                            "correction + WRITE_SIZE); sources: profiles/r01_wave_pmc_8pairs.csv, profiles/r01_exact_pmc_8pairs.csv")
     json.dump(traffic, open(tpath, "w"), indent=1)
     print(open(out + "_pmc_8pairs.csv").read())
+    # the block matcher's own run (collect.sh step 4)
+    ms = glob.glob(os.path.join(ROOT, "gpurun_out", "r01_matcher_stats", "**", "*kernel_stats.csv"), recursive=True)
+    if solver == "wave" and ms:
+        shutil.copy(sorted(ms, key=os.path.getmtime)[-1], os.path.join(ROOT, "profiles", "r01_matcher_kernel_stats.csv"))
+        lines = [ln for ln in open(os.path.join(ROOT, "gpurun_out", "r01_matcher_times.txt")) if ln.startswith(("matcher", "oracle"))]
+        open(os.path.join(ROOT, "profiles", "r01_matcher_times.txt"), "w").write(
+            "# tools/bm_time.py / tools/bm_cpu_time.py (profiles/collect.sh step 4); the last matcher line runs cv::StereoBM's default\n"
+            "# uniqueness (15) and texture (10) tests, the others the filter factory's setting (both off)\n" + "".join(lines))
 
 
 if __name__ == "__main__":

@@ -1,4 +1,5 @@
-"""Times the device block matcher (both views) on synthetic pairs: python tools/bm_time.py [W H ndisp wsz n]"""
+"""Times the device block matcher (both views) on synthetic pairs: python tools/bm_time.py [W H ndisp wsz n [uniq texture]]
+(uniq / texture: uniquenessRatio and textureThreshold of the LEFT matcher, default 0 as the filter factory sets them)"""
 import sys
 import time
 
@@ -16,6 +17,10 @@ right = torch.from_numpy(np.ascontiguousarray(np.roll(base, -9, 2)[:, :, 32:32 +
 lm = adf.StereoBM.create(nd, wsz)
 lm.setTextureThreshold(0); lm.setUniquenessRatio(0)
 rm = adf.createRightMatcher(lm)
+if len(sys.argv) > 6:
+    lm.setUniquenessRatio(int(sys.argv[6])); rm.setUniquenessRatio(int(sys.argv[6]))
+if len(sys.argv) > 7:
+    lm.setTextureThreshold(int(sys.argv[7])); rm.setTextureThreshold(int(sys.argv[7]))
 dl = torch.empty((n, H, W), dtype=torch.int16, device="cuda")
 dr = torch.empty_like(dl)
 for _ in range(2):
