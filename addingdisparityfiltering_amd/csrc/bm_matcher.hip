@@ -106,17 +106,17 @@ __device__ __forceinline__ uint32_t wave_scan(uint32_t v)
     return v;
 }
 
-#ifndef ADF_BM_CPL
-#define ADF_BM_CPL 4
-#endif
-constexpr int CPL = ADF_BM_CPL;        // adjacent columns per lane
-constexpr int TILE = 64 * CPL;         // columns per wave, window halo included
-constexpr int XPAD = TILE + 4;         // columns of padding right of a prefiltered row (lanes past the image read it)
+// adjacent columns per lane: four on the filter's path; two with the uniqueness test, whose four extra state
+// registers per pixel would otherwise push the kernel past 256 registers (measured: 3.3 ms instead of 3.05 per 4K pair)
+constexpr int cpl_of(bool uniq) { return uniq ? 2 : 4; }
+constexpr int XPAD = 64 * 4 + 4;       // columns of padding right of a prefiltered row (lanes past the image read it)
 constexpr int floordiv(int a, int b) { return (a >= 0) ? a / b : -((-a + b - 1) / b); }
 
 template <int W2, bool UNIQ>
 __global__ void __launch_bounds__(256) bm_match_kernel(MatchArgs a)
 {
+    constexpr int CPL = cpl_of(UNIQ);
+    constexpr int TILE = 64 * CPL;          // columns per wave, window halo included
     constexpr int TOUT = TILE - 2 * W2;
     constexpr int GB = (W2 + 3) / 4;        // groups above the output group that the windows reach
     constexpr int NG = 2 * GB + 1;
@@ -227,52 +227,38 @@ __global__ void __launch_bounds__(256) bm_match_kernel(MatchArgs a)
         }
     }
 
-    // winner, its disparity + 1, the costs one below / one above it, the previous cost; for the uniqueness test
-    // the smallest cost at least two below (lmin) / two above (rmin) the winner and the delayed prefix minima
-    uint32_t best[4][CPL], bk1[4][CPL], pAt[4][CPL], nAt[4][CPL], prev[4][CPL];
+    // Winner tracking, a pair of disparities (k, k+1 = low / high half of one register) at a time.  A pair is
+    // compared through its smaller half, and when it beats the winner the pair itself (capW), the pair before it
+    // (pAt) and -- one step later -- the pair after it (nAt) are kept as whole registers.  Which half won (the
+    // high one on a tie: ties go to the larger disparity) and which halves are the neighbours of the sub-pixel fit
+    // is decided once, at the end:
+    //   winner in the low half  (even k): below = high half of the previous pair, above = high half of capW
+    //   winner in the high half (odd k):  below = low half of capW,              above = low half of the next pair
+    // `after`: the previous pair became the winner (the previous step's compare result, kept in scalar registers).
+    // Uniqueness test (UNIQ): the smallest cost at least two disparities away from the winner = the smallest pair
+    // minimum at least two PAIRS before (lmin: the prefix minimum delayed by two steps, taken when the winner
+    // changes) or after it (rmin: restarted when the winner changes, fed from the second pair after it on), plus
+    // the halves of the two neighbouring pairs that are not adjacent to the winner -- read from pAt / nAt at the end.
+    uint32_t best[4][CPL], bk1[4][CPL], capW[4][CPL], pAt[4][CPL], nAt[4][CPL], prev[4][CPL];
     uint32_t lmin[4][CPL], rmin[4][CPL], pm1[4][CPL], pm2[4][CPL];
-#pragma unroll
-    for (int r = 0; r < 4; r++)
-#pragma unroll
-        for (int j = 0; j < CPL; j++) {
-            best[r][j] = INF; bk1[r][j] = 0x40000000u; pAt[r][j] = INF; nAt[r][j] = INF; prev[r][j] = INF;
-            lmin[r][j] = INF; rmin[r][j] = INF; pm1[r][j] = INF; pm2[r][j] = INF;
-        }
-    // `after`: the previous disparity became the winner, so this cost is the one above it (the flag is the
-    // previous step's compare result, carried in scalar registers)
     bool after[4][CPL];
 #pragma unroll
     for (int r = 0; r < 4; r++)
 #pragma unroll
-        for (int j = 0; j < CPL; j++) after[r][j] = false;
-    auto track = [&](int r, int j, uint32_t k, uint32_t s) {
-        const bool above = after[r][j];
-        if (above) nAt[r][j] = s;
-        const bool upd = s <= best[r][j];                   // ties go to the larger disparity
-        if (!upd && !above) rmin[r][j] = min(rmin[r][j], s);
-        if (upd) { lmin[r][j] = pm2[r][j]; rmin[r][j] = INF; }
-        pm2[r][j] = pm1[r][j]; pm1[r][j] = min(pm1[r][j], s);
-        if (upd) { pAt[r][j] = prev[r][j]; bk1[r][j] = k + 1u; }
-        best[r][j] = min(best[r][j], s);
-        prev[r][j] = s;
-        after[r][j] = upd;
-    };
-    // Without the uniqueness test only the winner and its two neighbours matter, and all three are captured as
-    // whole pair registers: a pair (disparities k, k+1) is compared through its smaller half, and when it beats
-    // the winner the pair itself (capW), the pair before it (pAt) and -- one step later -- the pair after it (nAt)
-    // are kept.  Which half won (the high one on a tie: ties go to the larger disparity) and which halves are the
-    // neighbours is decided once, at the end:
-    //   winner in the low half  (even k): below = high half of the previous pair, above = high half of capW
-    //   winner in the high half (odd k):  below = low half of capW,              above = low half of the next pair
-    uint32_t capW[4][CPL];
-#pragma unroll
-    for (int r = 0; r < 4; r++)
-#pragma unroll
-        for (int j = 0; j < CPL; j++) capW[r][j] = 0;
+        for (int j = 0; j < CPL; j++) {
+            best[r][j] = INF; bk1[r][j] = 1u; capW[r][j] = 0; pAt[r][j] = 0; nAt[r][j] = 0; prev[r][j] = 0;
+            lmin[r][j] = INF; rmin[r][j] = INF; pm1[r][j] = INF; pm2[r][j] = INF;
+            after[r][j] = false;
+        }
     auto track_pair = [&](int r, int j, uint32_t k, uint32_t Pk) {
         const uint32_t m = min(Pk & 0xFFFFu, Pk >> 16);
         const bool upd = m <= best[r][j];
         best[r][j] = min(best[r][j], m);
+        if (UNIQ) {
+            if (!upd && !after[r][j]) rmin[r][j] = min(rmin[r][j], m);
+            if (upd) { lmin[r][j] = pm2[r][j]; rmin[r][j] = INF; }
+            pm2[r][j] = pm1[r][j]; pm1[r][j] = min(pm1[r][j], m);
+        }
         if (after[r][j]) nAt[r][j] = Pk;
         if (upd) { capW[r][j] = Pk; pAt[r][j] = prev[r][j]; bk1[r][j] = k + 1u; }
         after[r][j] = upd;
@@ -307,14 +293,7 @@ __global__ void __launch_bounds__(256) bm_match_kernel(MatchArgs a)
         for (int r = 0; r < 4; r++) {
             horizontal(P[r], r);
 #pragma unroll
-            for (int j = 0; j < CPL; j++) {
-                if (UNIQ) {
-                    track(r, j, (uint32_t)k, P[r][j] & 0xFFFFu);
-                    track(r, j, (uint32_t)k + 1u, P[r][j] >> 16);
-                } else {
-                    track_pair(r, j, (uint32_t)k, P[r][j]);
-                }
-            }
+            for (int j = 0; j < CPL; j++) track_pair(r, j, (uint32_t)k, P[r][j]);
         }
     }
 
@@ -328,16 +307,14 @@ __global__ void __launch_bounds__(256) bm_match_kernel(MatchArgs a)
         for (int j = 0; j < CPL; j++) {
             const int t = lane * CPL + j;
             if (t < W2 || t >= TILE - W2 || c + j >= a.xe) continue;
-            int kb = (int)bk1[r][j] - 1;
+            const int kw = (int)bk1[r][j] - 1;                            // first disparity of the winner pair
             const int sb = (int)best[r][j];
-            uint32_t below = pAt[r][j], above = nAt[r][j];
-            if (!UNIQ) {                                                   // packed captures: kb is the pair's even disparity
-                const uint32_t wl = capW[r][j] & 0xFFFFu, wh = capW[r][j] >> 16;
-                const bool odd = wh <= wl;
-                below = odd ? wl : (below >> 16);
-                above = odd ? (above & 0xFFFFu) : wh;
-                kb += odd ? 1 : 0;
-            }
+            const uint32_t wl = capW[r][j] & 0xFFFFu, wh = capW[r][j] >> 16;
+            const uint32_t bl = pAt[r][j] & 0xFFFFu, bh = pAt[r][j] >> 16;  // the pair before (if kw > 0)
+            const uint32_t al = nAt[r][j] & 0xFFFFu, ah = nAt[r][j] >> 16;  // the pair after (if kw + 2 < ndisp)
+            const bool odd = wh <= wl;
+            const int kb = kw + (odd ? 1 : 0);
+            const uint32_t below = odd ? wl : bh, above = odd ? al : wh;
             const int pv = (int)(kb > 0 ? below : above);
             const int nv = (int)(kb < a.ndisp - 1 ? above : below);
             const int dd = pv + nv - 2 * sb + abs(pv - nv);
@@ -345,7 +322,10 @@ __global__ void __launch_bounds__(256) bm_match_kernel(MatchArgs a)
             if ((int)tex[r][j] < a.texthr) out = filtered;
             if (UNIQ) {
                 const int thresh = sb + sb * a.uniq / 100;
-                if ((int)min(lmin[r][j], rmin[r][j]) <= thresh) out = filtered;
+                uint32_t other = min(lmin[r][j], rmin[r][j]);
+                if (kw > 0) other = min(other, odd ? min(bl, bh) : bl);                // kb-1 is adjacent, kb-2 and kb-3 are not
+                if (kw + 2 < a.ndisp) other = min(other, odd ? ah : min(al, ah));      // kb+1 is adjacent, kb+2 and kb+3 are not
+                if ((int)other <= thresh) out = filtered;
             }
             drow[c + j] = out;
         }
@@ -366,7 +346,7 @@ __global__ void __launch_bounds__(256) bm_border_kernel(MatchArgs a)
 template <bool UNIQ>
 hipError_t launch_match(const MatchArgs& a, int w2, dim3 block, int n, hipStream_t st)
 {
-    const int tout = TILE - 2 * w2;
+    const int tout = 64 * cpl_of(UNIQ) - 2 * w2;
     dim3 grid((a.xe - a.xs + tout - 1) / tout, (a.HG + 3) / 4, n);
     switch (w2) {
 #define ADF_BM_CASE(K) case K: hipLaunchKernelGGL((bm_match_kernel<K, UNIQ>), grid, block, 0, st, a); break;

@@ -40,6 +40,9 @@ def test_every_block_size_bit_exact(adf, oracle, wsz):
     (41, 150, 64, 11, -20, 15, 0, 30),     # range straddling zero
     (22, 300, 128, 21, 0, 1, 0, 0),        # widest window, smallest cap
     (9, 90, 16, 7, 0, 31, 0, 0),           # fewer rows than two row groups
+    (30, 200, 32, 21, 0, 31, 5, 20),       # uniqueness instantiation (two columns per lane), widest window
+    (25, 150, 16, 5, -3, 31, 0, 10),       # ... narrowest window
+    (33, 700, 48, 13, 0, 31, 0, 12),       # ... several column tiles
 ])
 def test_parameter_corners_bit_exact(adf, oracle, H, W, nd, wsz, md, cap, texthr, uniq):
     left, right = _views(H * W, H, W, shift=7)
