@@ -197,7 +197,6 @@ __global__ void __launch_bounds__(NT) discontinuity_col_kernel(DiscArgs a)
 #pragma unroll
         for (int s = 0; s < U; s++) {
             const int n = n0 + s;
-            constexpr int dummy = 0; (void)dummy;
             const int slot = s % K;                               // compile-time after unrolling
             if (n < nrows) {                                     // block-uniform
                 rowbuf[n & 1][tid] = WinSum::stage(cur[s]);

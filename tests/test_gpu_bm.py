@@ -148,3 +148,17 @@ def test_random_parameters_bit_exact(adf, oracle):
         got = _bm(adf, nd, wsz, md, cap, texthr, uniq).compute(left, right)
         exp = oracle.bm_compute(left, right, nd, wsz, md, cap, texthr, uniq)
         assert np.array_equal(got, exp), (case, H, W, nd, wsz, md, cap, texthr, uniq)
+
+
+def test_host_batch_with_row_padding(adf, oracle):
+    """adf_bm_compute_host on a batch of numpy pairs whose rows carry padding (strides larger than the width)."""
+    N, H, W = 2, 37, 150
+    pairs = [_views(300 + i, H, W, shift=4 + i) for i in range(N)]
+    bl = np.zeros((N, H, W + 9), np.uint8); br = np.zeros((N, H, W + 5), np.uint8)
+    for i, (l, r) in enumerate(pairs):
+        bl[i, :, :W] = l; br[i, :, :W] = r
+    out = np.full((N, H, W + 3), 555, np.int16)
+    _bm(adf, 32, 11, 0, 31, 10, 15).compute(bl[:, :, :W], br[:, :, :W], out[:, :, :W])
+    assert (out[:, :, W:] == 555).all()
+    for i, (l, r) in enumerate(pairs):
+        assert np.array_equal(out[i, :, :W], oracle.bm_compute(l, r, 32, 11, 0, 31, 10, 15))
