@@ -14,16 +14,17 @@
 // groups of replicated rows pad the top and the bottom.  One v_sad_u8 / v_msad_u8 then adds four rows of one
 // column of the SAD window, and a lane reads its four adjacent columns of a group as one 16-byte load.
 //
-// Kernel.  One wave = 256 adjacent columns, four per lane (the outer W2 on each side are window halo) x one
-// group of four output rows; the four waves of a workgroup take four consecutive row groups.  Per disparity
+// Kernel.  One wave = 256 adjacent columns, four per lane (128, two per lane, in the instantiation with the
+// uniqueness test; the outer W2 on each side are window halo) x one group of four output rows; the four waves of a workgroup take four consecutive row groups.  Per disparity
 // and column a lane forms the four vertical window sums (groups fully inside all four windows are summed
 // once, the partial ones through v_msad_u8 with the rows outside the window zeroed in the left operand), two
 // disparities are packed in one register (low / high half; a window sum is below 2^16, and the prefix
 // arithmetic is exact modulo 2^32), a local prefix plus one DPP wave scan of the lane totals gives the prefix
-// over the tile's columns, the neighbours' prefix vectors come through a per-wave LDS slot, and the winner
-// with its two neighbours (and, for the uniqueness test, the smallest cost away from the winner) is tracked in
-// registers while the disparities stream by.  Nothing but the int16 result is written.
-// The kernel is bound by integer VALU issue (about 14 instructions per pixel and disparity), not
+// over the tile's columns, the neighbours' prefix vectors come through a per-wave LDS slot, and the winner is
+// tracked a pair of disparities at a time: the winner pair and the pairs before / after it are captured as whole
+// registers (for the uniqueness test also the smallest pair minimum two or more pairs away), and which half won
+// is decided once at the end.  Nothing but the int16 result is written.
+// The kernel is bound by integer VALU issue (about 11 instructions per pixel and disparity), not
 // by HBM: the views are read through L1/L2 once per disparity, HBM sees them once.
 #include "adf_internal.h"
 #include "../../include/adf_wls.h"
@@ -107,7 +108,8 @@ __device__ __forceinline__ uint32_t wave_scan(uint32_t v)
 }
 
 // adjacent columns per lane: four on the filter's path; two with the uniqueness test, whose four extra state
-// registers per pixel would otherwise push the kernel past 256 registers (measured: 3.3 ms instead of 3.05 per 4K pair)
+// registers per pixel would otherwise push the kernel past 256 registers (measured per 4K pair: 3.3 ms with four
+// columns, 1.98 ms with two)
 constexpr int cpl_of(bool uniq) { return uniq ? 2 : 4; }
 constexpr int XPAD = 64 * 4 + 4;       // columns of padding right of a prefiltered row (lanes past the image read it)
 constexpr int floordiv(int a, int b) { return (a >= 0) ? a / b : -((-a + b - 1) / b); }
