@@ -370,6 +370,10 @@ class StereoSGBM(StereoMatcher):
     def getPreFilterCap(self): return self.preFilterCap
     def setPreFilterCap(self, v): self.preFilterCap = v
 
+    def compute(self, left, right, disparity=None):
+        """Not built: the semi-global matcher is a parameter holder for the factories only."""
+        raise AdfError(_lib.ADF_EBADARG, "StereoSGBM.compute is not implemented on the device; StereoBM.compute is")
+
 
 def createDisparityWLSFilter(matcher_left):
     """DF.hpp:131, DF.cpp:386-414: set the filter up from the matcher (and mutate the matcher)."""

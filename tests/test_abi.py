@@ -77,6 +77,8 @@ def test_matcher_factories_host_logic():
         adf.createRightMatcher(adf.StereoMatcher())
     with pytest.raises(adf.AdfError):
         adf.createDisparityWLSFilter(adf.StereoMatcher())
+    with pytest.raises(adf.AdfError):                       # the semi-global matcher is a parameter holder only
+        right.compute(np.zeros((8, 8), np.uint8), np.zeros((8, 8), np.uint8))
 
 
 def test_synthetic_example_shape_and_determinism():
