@@ -442,6 +442,7 @@ static int bm_check(const adf_bm* h, int n, const void* l, const void* r, const 
     if (!h) return bm_fail(ADF_EBADARG, "handle is NULL");
     if (n <= 0 || !l || !r || !d) return bm_fail(ADF_EBADARG, "views and disparity must be non-NULL, n_pairs positive");
     if (W <= 0 || H <= 0 || ls < W || rs < W || dstr < (ptrdiff_t)W * 2) return bm_fail(ADF_ESIZE, "bad size or stride");
+    if ((dstr & 1) || (reinterpret_cast<uintptr_t>(d) & 1)) return bm_fail(ADF_ESIZE, "disparity rows must be 2-byte aligned");
     // the checks cv::StereoBM::compute makes on its parameters; the window is limited to 21 so that a
     // window sum fits 16 bits
     if (h->num_disp <= 0 || h->num_disp % 16) return bm_fail(ADF_EBADARG, "numDisparities must be positive and divisible by 16");
@@ -462,6 +463,7 @@ extern "C" int adf_bm_compute_device(adf_bm_t* h, int n_pairs,
 {
     int rc = bm_check(h, n_pairs, left, right, disparity, W, H, left_stride, right_stride, disp_stride);
     if (rc) return rc;
+    if (n_pairs > 1 && (disp_pair_stride & 1)) return bm_fail(ADF_ESIZE, "disparity maps must be 2-byte aligned");
     DevScope ds(h->device);
     hipStream_t st = (hipStream_t)stream;
     const int HG = (H + 3) / 4, HGP = HG + 2 * PG;
