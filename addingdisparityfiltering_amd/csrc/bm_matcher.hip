@@ -124,7 +124,8 @@ __global__ void __launch_bounds__(256) bm_match_kernel(MatchArgs a)
     constexpr int NG = 2 * GB + 1;
     static_assert(GB <= PG, "padding too small for this window");
 
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // uniform: row bases and the LDS slot stay scalar
     const int g = blockIdx.y * 4 + wave;
     if (g >= a.HG) return;                                           // whole wave; no barrier below
     const int c = a.xs + (int)blockIdx.x * TOUT - W2 + lane * CPL;   // this lane's first column (>= 0)
@@ -133,9 +134,11 @@ __global__ void __launch_bounds__(256) bm_match_kernel(MatchArgs a)
     const uint32_t* __restrict__ Lt = a.Lt + voff;
     const uint32_t* __restrict__ Rt = a.Rt + voff;
 
-    auto load4 = [&](const uint32_t* row, unsigned x, uint32_t (&d)[CPL]) {   // x .. x+3 are inside the padded row
-        struct __attribute__((aligned(4))) Vec { uint32_t v[CPL]; };     // one dword-aligned vector load
-        const Vec q = *reinterpret_cast<const Vec*>(row + x);
+    // one dword-aligned vector load of CPL adjacent columns; the byte offset is formed in 32 bits so that the load
+    // takes the scalar row base plus a 32-bit vector offset
+    auto load4 = [&](const uint32_t* row, unsigned x, uint32_t (&d)[CPL]) {   // x .. x+CPL-1 are inside the padded row
+        struct __attribute__((aligned(4))) Vec { uint32_t v[CPL]; };
+        const Vec q = *reinterpret_cast<const Vec*>(reinterpret_cast<const char*>(row) + x * 4u);
 #pragma unroll
         for (int j = 0; j < CPL; j++) d[j] = q.v[j];
     };
