@@ -82,6 +82,7 @@ SYMBOLS = [
     ("adf_bm_set_params", _i, [_vp, _i, _i, _i, _i, _i, _i]),
     ("adf_bm_get_params", _i, [_vp] + [C.POINTER(_i)] * 6),
     ("adf_bm_compute_device", _i, [_vp, _i, _vp, _pd, _pd, _vp, _pd, _pd, _i, _i, _vp, _pd, _pd, _vp]),
+    ("adf_bm_compute_both_device", _i, [_vp, _i, _vp, _pd, _pd, _vp, _pd, _pd, _i, _i, _vp, _pd, _pd, _vp, _pd, _pd, _vp]),
     ("adf_bm_compute_host", _i, [_vp, _i, _vp, _pd, _pd, _vp, _pd, _pd, _i, _i, _vp, _pd, _pd]),
 ]
 

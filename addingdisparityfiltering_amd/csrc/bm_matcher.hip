@@ -65,13 +65,23 @@ __global__ void __launch_bounds__(256) bm_prefilter_kernel(PrefilterArgs a)
     a.dst[(size_t)blockIdx.z * a.dst_pair + (size_t)gp * a.Wp + x] = out;
 }
 
-struct MatchArgs {
-    const uint32_t* Lt; const uint32_t* Rt; size_t t_pair;   // prefiltered views, dwords per view
+// One view's search: its prefiltered "left" (reference) and "right" (searched) images, output and disparity range.
+struct ViewArgs {
+    const uint32_t* Lt; const uint32_t* Rt;                  // prefiltered views, t_pair dwords per image
     int16_t* disp; ptrdiff_t dstride, dpair;                 // bytes
-    int W, Wp, H, HG;                                        // Wp: dwords per prefiltered row (W + XPAD, multiple of 4)
-    int mindisp, ndisp;
+    int mindisp;
     int xs, xe;            // matched columns [xs, xe)
-    int cap, texthr, uniq;
+    int texthr, uniq;
+};
+// A launch matches one view per image pair (nviews = 1: StereoMatcher::compute) or both views of every pair
+// (nviews = 2: the left matcher and the right matcher of disparity_filters.cpp:417-431 in one grid, blockIdx.z =
+// 2 * pair + view; the two views' searches are the same size, so one grid covers both).
+struct MatchArgs {
+    ViewArgs v[2];
+    int nviews;
+    size_t t_pair;
+    int W, Wp, H, HG;                                        // Wp: dwords per prefiltered row (W + XPAD, multiple of 4)
+    int ndisp, cap;
 };
 
 // rows of group gi (relative to the output group) that lie in the window of output row r
@@ -128,11 +138,16 @@ __global__ void __launch_bounds__(256) bm_match_kernel(MatchArgs a)
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // uniform: row bases and the LDS slot stay scalar
     const int g = blockIdx.y * 4 + wave;
     if (g >= a.HG) return;                                           // whole wave; no barrier below
-    const int c = a.xs + (int)blockIdx.x * TOUT - W2 + lane * CPL;   // this lane's first column (>= 0)
+    const int vi = a.nviews == 2 ? (int)(blockIdx.z & 1) : 0;
+    const unsigned pz = a.nviews == 2 ? blockIdx.z >> 1 : blockIdx.z;
+    const ViewArgs& va = a.v[vi];
+    const int xs = va.xs, xe = va.xe, mindisp = va.mindisp, texthr = va.texthr, uniq = va.uniq;
+    if (xs + (int)blockIdx.x * TOUT >= xe) return;                  // tile past this view's matched columns
+    const int c = xs + (int)blockIdx.x * TOUT - W2 + lane * CPL;     // this lane's first column (>= 0)
     const int Wp = a.Wp;
-    const size_t voff = (size_t)blockIdx.z * a.t_pair + (size_t)(g - GB + PG) * Wp;
-    const uint32_t* __restrict__ Lt = a.Lt + voff;
-    const uint32_t* __restrict__ Rt = a.Rt + voff;
+    const size_t voff = (size_t)pz * a.t_pair + (size_t)(g - GB + PG) * Wp;
+    const uint32_t* __restrict__ Lt = va.Lt + voff;
+    const uint32_t* __restrict__ Rt = va.Rt + voff;
 
     // one dword-aligned vector load of CPL adjacent columns; the byte offset is formed in 32 bits so that the load
     // takes the scalar row base plus a 32-bit vector offset
@@ -212,7 +227,7 @@ __global__ void __launch_bounds__(256) bm_match_kernel(MatchArgs a)
     for (int r = 0; r < 4; r++)
 #pragma unroll
         for (int j = 0; j < CPL; j++) tex[r][j] = INF;
-    if (a.texthr > 0) {
+    if (texthr > 0) {
         uint32_t Rd[NG][CPL], V[CPL][4];
         const uint32_t ft = (uint32_t)(a.cap + 1) * 0x01010101u;
 #pragma unroll
@@ -270,7 +285,7 @@ __global__ void __launch_bounds__(256) bm_match_kernel(MatchArgs a)
         prev[r][j] = Pk;
     };
 
-    const int xbase = c - a.mindisp;                         // R column of disparity index 0; xbase - k >= 0 for matched columns
+    const int xbase = c - mindisp;                           // R column of disparity index 0; xbase - k >= 0 for matched columns
     auto rcol = [&](int k) -> unsigned { return (unsigned)min(max(xbase - k, 0), Wp - CPL); };
     uint32_t R0[NG][CPL], R1[NG][CPL];
     {
@@ -302,16 +317,16 @@ __global__ void __launch_bounds__(256) bm_match_kernel(MatchArgs a)
         }
     }
 
-    const int16_t filtered = (int16_t)((a.mindisp - 1) * 16);
+    const int16_t filtered = (int16_t)((mindisp - 1) * 16);
 #pragma unroll
     for (int r = 0; r < 4; r++) {
         const int y = 4 * g + r;
         if (y >= a.H) continue;
-        int16_t* drow = reinterpret_cast<int16_t*>(reinterpret_cast<char*>(a.disp) + (ptrdiff_t)blockIdx.z * a.dpair + (ptrdiff_t)y * a.dstride);
+        int16_t* drow = reinterpret_cast<int16_t*>(reinterpret_cast<char*>(va.disp) + (ptrdiff_t)pz * va.dpair + (ptrdiff_t)y * va.dstride);
 #pragma unroll
         for (int j = 0; j < CPL; j++) {
             const int t = lane * CPL + j;
-            if (t < W2 || t >= TILE - W2 || c + j >= a.xe) continue;
+            if (t < W2 || t >= TILE - W2 || c + j >= xe) continue;
             const int kw = (int)bk1[r][j] - 1;                            // first disparity of the winner pair
             const int sb = (int)best[r][j];
             const uint32_t wl = capW[r][j] & 0xFFFFu, wh = capW[r][j] >> 16;
@@ -323,10 +338,10 @@ __global__ void __launch_bounds__(256) bm_match_kernel(MatchArgs a)
             const int pv = (int)(kb > 0 ? below : above);
             const int nv = (int)(kb < a.ndisp - 1 ? above : below);
             const int dd = pv + nv - 2 * sb + abs(pv - nv);
-            int16_t out = (int16_t)(((kb + a.mindisp) * 256 + (dd != 0 ? (pv - nv) * 256 / dd : 0) + 15) >> 4);
-            if ((int)tex[r][j] < a.texthr) out = filtered;
-            if (UNIQ) {
-                const int thresh = sb + sb * a.uniq / 100;
+            int16_t out = (int16_t)(((kb + mindisp) * 256 + (dd != 0 ? (pv - nv) * 256 / dd : 0) + 15) >> 4);
+            if ((int)tex[r][j] < texthr) out = filtered;
+            if (UNIQ && uniq > 0) {                                       // (a view of the launch may have the test off)
+                const int thresh = sb + sb * uniq / 100;
                 uint32_t other = min(lmin[r][j], rmin[r][j]);
                 if (kw > 0) other = min(other, odd ? min(bl, bh) : bl);                // kb-1 is adjacent, kb-2 and kb-3 are not
                 if (kw + 2 < a.ndisp) other = min(other, odd ? ah : min(al, ah));      // kb+1 is adjacent, kb+2 and kb+3 are not
@@ -341,10 +356,13 @@ __global__ void __launch_bounds__(256) bm_match_kernel(MatchArgs a)
 __global__ void __launch_bounds__(256) bm_border_kernel(MatchArgs a)
 {
     const int y = blockIdx.y;
-    const int nleft = max(min(a.xs, a.W), 0), xr = (a.xe > a.xs) ? max(a.xe, nleft) : nleft;
+    const int vi = a.nviews == 2 ? (int)(blockIdx.z & 1) : 0;
+    const unsigned pz = a.nviews == 2 ? blockIdx.z >> 1 : blockIdx.z;
+    const ViewArgs& va = a.v[vi];
+    const int nleft = max(min(va.xs, a.W), 0), xr = (va.xe > va.xs) ? max(va.xe, nleft) : nleft;
     const int n = nleft + (a.W - xr);
-    const int16_t filtered = (int16_t)((a.mindisp - 1) * 16);
-    int16_t* row = reinterpret_cast<int16_t*>(reinterpret_cast<char*>(a.disp) + (ptrdiff_t)blockIdx.z * a.dpair + (ptrdiff_t)y * a.dstride);
+    const int16_t filtered = (int16_t)((va.mindisp - 1) * 16);
+    int16_t* row = reinterpret_cast<int16_t*>(reinterpret_cast<char*>(va.disp) + (ptrdiff_t)pz * va.dpair + (ptrdiff_t)y * va.dstride);
     for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) row[i < nleft ? i : xr + (i - nleft)] = filtered;
 }
 
@@ -352,7 +370,9 @@ template <bool UNIQ>
 hipError_t launch_match(const MatchArgs& a, int w2, dim3 block, int n, hipStream_t st)
 {
     const int tout = 64 * cpl_of(UNIQ) - 2 * w2;
-    dim3 grid((a.xe - a.xs + tout - 1) / tout, (a.HG + 3) / 4, n);
+    int cols = a.v[0].xe - a.v[0].xs;
+    if (a.nviews == 2 && a.v[1].xe - a.v[1].xs > cols) cols = a.v[1].xe - a.v[1].xs;
+    dim3 grid((cols + tout - 1) / tout, (a.HG + 3) / 4, n * a.nviews);
     switch (w2) {
 #define ADF_BM_CASE(K) case K: hipLaunchKernelGGL((bm_match_kernel<K, UNIQ>), grid, block, 0, st, a); break;
     ADF_BM_CASE(2) ADF_BM_CASE(3) ADF_BM_CASE(4) ADF_BM_CASE(5) ADF_BM_CASE(6)
@@ -457,18 +477,28 @@ static int bm_check(const adf_bm* h, int n, const void* l, const void* r, const 
     return ADF_OK;
 }
 
-extern "C" int adf_bm_compute_device(adf_bm_t* h, int n_pairs,
-                                     const uint8_t* left, ptrdiff_t left_stride, ptrdiff_t left_pair_stride,
-                                     const uint8_t* right, ptrdiff_t right_stride, ptrdiff_t right_pair_stride,
-                                     int W, int H,
-                                     int16_t* disparity, ptrdiff_t disp_stride, ptrdiff_t disp_pair_stride,
-                                     void* stream)
+// Shared body: prefilter both images once, then one launch for the left view alone (disp_right == NULL) or for
+// both views.
+static int bm_compute_impl(adf_bm_t* h, int n_pairs,
+                           const uint8_t* left, ptrdiff_t left_stride, ptrdiff_t left_pair_stride,
+                           const uint8_t* right, ptrdiff_t right_stride, ptrdiff_t right_pair_stride,
+                           int W, int H,
+                           int16_t* disp_left, ptrdiff_t dl_stride, ptrdiff_t dl_pair_stride,
+                           int16_t* disp_right, ptrdiff_t dr_stride, ptrdiff_t dr_pair_stride,
+                           hipStream_t st)
 {
-    int rc = bm_check(h, n_pairs, left, right, disparity, W, H, left_stride, right_stride, disp_stride);
+    int rc = bm_check(h, n_pairs, left, right, disp_left, W, H, left_stride, right_stride, dl_stride);
     if (rc) return rc;
-    if (n_pairs > 1 && (disp_pair_stride & 1)) return bm_fail(ADF_ESIZE, "disparity maps must be 2-byte aligned");
+    if (n_pairs > 1 && (dl_pair_stride & 1)) return bm_fail(ADF_ESIZE, "disparity maps must be 2-byte aligned");
+    const int nviews = disp_right ? 2 : 1;
+    if (disp_right) {
+        if (dr_stride < (ptrdiff_t)W * 2 || (dr_stride & 1) || (reinterpret_cast<uintptr_t>(disp_right) & 1) ||
+            (n_pairs > 1 && (dr_pair_stride & 1)))
+            return bm_fail(ADF_ESIZE, "bad stride or alignment of the right disparity map");
+        if (h->min_disp + h->num_disp - 1 > 32767 || -(h->min_disp + h->num_disp) + 1 < -32768)
+            return bm_fail(ADF_EBADARG, "disparity range of the right-view matcher does not fit");
+    }
     DevScope ds(h->device);
-    hipStream_t st = (hipStream_t)stream;
     const int HG = (H + 3) / 4, HGP = HG + 2 * PG;
     const int Wp = (W + XPAD + 3) / 4 * 4;                     // padded row: lanes past the image read (and discard) it
     const size_t view = (size_t)HGP * Wp;                      // dwords per prefiltered view
@@ -485,17 +515,26 @@ extern "C" int adf_bm_compute_device(adf_bm_t* h, int n_pairs,
     p.src = right; p.stride = right_stride; p.pair_stride = right_pair_stride; p.dst = Rt;
     hipLaunchKernelGGL(bm_prefilter_kernel, pgrid, dim3(256), 0, st, p);
 
+    const int w2 = h->block / 2;
+    auto view_args = [&](const uint32_t* ref, const uint32_t* srch, int16_t* d, ptrdiff_t ds_, ptrdiff_t dp, int md, int texthr, int uniq) {
+        ViewArgs v;
+        v.Lt = ref; v.Rt = srch; v.disp = d; v.dstride = ds_; v.dpair = dp;
+        v.mindisp = md;
+        const int maxd = md + h->num_disp - 1;
+        v.xs = (maxd > 0 ? maxd : 0) + w2;
+        v.xe = W - (md < 0 ? -md : 0) - w2;
+        v.texthr = texthr; v.uniq = uniq;
+        return v;
+    };
     MatchArgs a;
-    a.Lt = Lt; a.Rt = Rt; a.t_pair = view;
-    a.disp = disparity; a.dstride = disp_stride; a.dpair = disp_pair_stride;
-    a.W = W; a.Wp = Wp; a.H = H; a.HG = HG;
-    a.mindisp = h->min_disp; a.ndisp = h->num_disp;
-    const int w2 = h->block / 2, maxd = h->min_disp + h->num_disp - 1;
-    a.xs = (maxd > 0 ? maxd : 0) + w2;
-    a.xe = W - (h->min_disp < 0 ? -h->min_disp : 0) - w2;
-    a.cap = h->cap; a.texthr = h->texthr; a.uniq = h->uniq;
-    hipLaunchKernelGGL(bm_border_kernel, dim3(4, H, n_pairs), dim3(256), 0, st, a);
-    if (a.xe > a.xs) {
+    a.nviews = nviews; a.t_pair = view;
+    a.W = W; a.Wp = Wp; a.H = H; a.HG = HG; a.ndisp = h->num_disp; a.cap = h->cap;
+    a.v[0] = view_args(Lt, Rt, disp_left, dl_stride, dl_pair_stride, h->min_disp, h->texthr, h->uniq);
+    // the right-view matcher of createRightMatcher (disparity_filters.cpp:421-431): views swapped,
+    // minDisparity = -(min_disp + num_disp) + 1, texture and uniqueness tests off
+    a.v[1] = disp_right ? view_args(Rt, Lt, disp_right, dr_stride, dr_pair_stride, -(h->min_disp + h->num_disp) + 1, 0, 0) : a.v[0];
+    hipLaunchKernelGGL(bm_border_kernel, dim3(4, H, n_pairs * nviews), dim3(256), 0, st, a);
+    if (a.v[0].xe > a.v[0].xs || (nviews == 2 && a.v[1].xe > a.v[1].xs)) {
         hipError_t e = h->uniq > 0 ? launch_match<true>(a, w2, dim3(256), n_pairs, st)
                                    : launch_match<false>(a, w2, dim3(256), n_pairs, st);
         if (e != hipSuccess) return bm_fail(ADF_EHIP, hipGetErrorString(e));
@@ -503,6 +542,31 @@ extern "C" int adf_bm_compute_device(adf_bm_t* h, int n_pairs,
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return bm_fail(ADF_EHIP, hipGetErrorString(e));
     return ADF_OK;
+}
+
+extern "C" int adf_bm_compute_device(adf_bm_t* h, int n_pairs,
+                                     const uint8_t* left, ptrdiff_t left_stride, ptrdiff_t left_pair_stride,
+                                     const uint8_t* right, ptrdiff_t right_stride, ptrdiff_t right_pair_stride,
+                                     int W, int H,
+                                     int16_t* disparity, ptrdiff_t disp_stride, ptrdiff_t disp_pair_stride,
+                                     void* stream)
+{
+    return bm_compute_impl(h, n_pairs, left, left_stride, left_pair_stride, right, right_stride, right_pair_stride, W, H,
+                           disparity, disp_stride, disp_pair_stride, nullptr, 0, 0, (hipStream_t)stream);
+}
+
+extern "C" int adf_bm_compute_both_device(adf_bm_t* h, int n_pairs,
+                                          const uint8_t* left, ptrdiff_t left_stride, ptrdiff_t left_pair_stride,
+                                          const uint8_t* right, ptrdiff_t right_stride, ptrdiff_t right_pair_stride,
+                                          int W, int H,
+                                          int16_t* disp_left, ptrdiff_t disp_left_stride, ptrdiff_t disp_left_pair_stride,
+                                          int16_t* disp_right, ptrdiff_t disp_right_stride, ptrdiff_t disp_right_pair_stride,
+                                          void* stream)
+{
+    if (!disp_right) return bm_fail(ADF_EBADARG, "disp_right is NULL");
+    return bm_compute_impl(h, n_pairs, left, left_stride, left_pair_stride, right, right_stride, right_pair_stride, W, H,
+                           disp_left, disp_left_stride, disp_left_pair_stride,
+                           disp_right, disp_right_stride, disp_right_pair_stride, (hipStream_t)stream);
 }
 
 extern "C" int adf_bm_compute_host(adf_bm_t* h, int n_pairs,

@@ -351,6 +351,40 @@ class StereoBM(StereoMatcher):
             _lib.check(lib.adf_bm_compute_host(*args))
         return disparity
 
+    def computeBoth(self, left, right, disparity_left=None, disparity_right=None):
+        """Extension: this matcher's map AND the map of createRightMatcher(self) (DF.cpp:417-431) from one launch --
+        identical to `self.compute(left, right)` and `createRightMatcher(self).compute(right, left)`, with the views
+        prefiltered once and both searches in one grid (worth it for one pair per call).  Device tensors only."""
+        batched = len(left.shape) == 3
+        L = _Image(left, np.uint8, "left", batched)
+        R = _Image(right, np.uint8, "right", batched)
+        if not (L.device and R.device):
+            raise AdfError(_lib.ADF_EBADARG, "computeBoth takes device tensors; use two compute() calls on the host")
+        if (L.n, L.h, L.w) != (R.n, R.h, R.w):
+            raise AdfError(_lib.ADF_ESIZE, "All the images must have the same size")
+        if (self.disp12MaxDiff >= 0 and self.disp12MaxDiff < 1000000) or self.speckleWindowSize > 0:
+            raise AdfError(_lib.ADF_EBADARG, "the matcher's own left-right check and speckle filter are not implemented")
+        if disparity_left is None:
+            disparity_left = _out_like(L, batched, np.int16)
+        if disparity_right is None:
+            disparity_right = _out_like(L, batched, np.int16)
+        DL = _Image(disparity_left, np.int16, "disparity_left", batched)
+        DR = _Image(disparity_right, np.int16, "disparity_right", batched)
+        for D in (DL, DR):
+            if (D.n, D.h, D.w) != (L.n, L.h, L.w) or not D.device:
+                raise AdfError(_lib.ADF_ESIZE, "disparity maps must match the views")
+        lib = _lib.lib()
+        if self._h is None:
+            h = C.c_void_p()
+            _lib.check(lib.adf_bm_create(C.byref(h), int(self.numDisparities), int(self.blockSize)))
+            self._h = h
+        _lib.check(lib.adf_bm_set_params(self._h, int(self.minDisparity), int(self.numDisparities), int(self.blockSize),
+                                         int(self.preFilterCap), int(self.textureThreshold), int(self.uniquenessRatio)))
+        _lib.check(lib.adf_bm_compute_both_device(
+            self._h, L.n, C.c_void_p(L.ptr), L.stride, L.pair_stride, C.c_void_p(R.ptr), R.stride, R.pair_stride, L.w, L.h,
+            C.c_void_p(DL.ptr), DL.stride, DL.pair_stride, C.c_void_p(DR.ptr), DR.stride, DR.pair_stride, _stream_of(L)))
+        return disparity_left, disparity_right
+
 
 class StereoSGBM(StereoMatcher):
     def __init__(self, minDisparity=0, numDisparities=16, blockSize=3, P1=0, P2=0, mode=0, preFilterCap=0):

@@ -99,7 +99,7 @@ def views_to_filtered(xi, view, roi, radius, n, num_disp, block):
     ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
     for it in range(2):                                      # first round warms the workspaces up
         ev[0].record()
-        lm.compute(left, right, dl); rm.compute(right, left, dr)
+        lm.computeBoth(left, right, dl, dr)                  # = lm.compute(left, right), rm.compute(right, left)
         ev[1].record()
         wls.filter(dl, view[:n], out, dr)
         ev[2].record()

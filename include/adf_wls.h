@@ -249,6 +249,18 @@ int adf_bm_compute_device(adf_bm_t* h, int n_pairs,
                           int W, int H,
                           int16_t* disparity, ptrdiff_t disp_stride, ptrdiff_t disp_pair_stride,
                           void* stream);
+/* Extension (not a cv:: call): the left-view map of adf_bm_compute_device AND the map of the right-view matcher of
+ * createRightMatcher (disparity_filters.cpp:417-431: views swapped, minDisparity = -(min_disp+num_disp)+1, texture
+ * and uniqueness tests off) from one launch -- the two images are prefiltered once and both searches share a grid,
+ * which matters for a single pair per call (1920x1080: 0.36 ms for two calls).  Results are identical to the two
+ * separate computes. */
+int adf_bm_compute_both_device(adf_bm_t* h, int n_pairs,
+                               const uint8_t* left, ptrdiff_t left_stride, ptrdiff_t left_pair_stride,
+                               const uint8_t* right, ptrdiff_t right_stride, ptrdiff_t right_pair_stride,
+                               int W, int H,
+                               int16_t* disp_left, ptrdiff_t disp_left_stride, ptrdiff_t disp_left_pair_stride,
+                               int16_t* disp_right, ptrdiff_t disp_right_stride, ptrdiff_t disp_right_pair_stride,
+                               void* stream);
 int adf_bm_compute_host(adf_bm_t* h, int n_pairs,
                         const uint8_t* left, ptrdiff_t left_stride, ptrdiff_t left_pair_stride,
                         const uint8_t* right, ptrdiff_t right_stride, ptrdiff_t right_pair_stride,

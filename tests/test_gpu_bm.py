@@ -162,3 +162,24 @@ def test_host_batch_with_row_padding(adf, oracle):
     assert (out[:, :, W:] == 555).all()
     for i, (l, r) in enumerate(pairs):
         assert np.array_equal(out[i, :, :W], oracle.bm_compute(l, r, 32, 11, 0, 31, 10, 15))
+
+
+@pytest.mark.parametrize("nd,wsz,md,texthr,uniq", [(32, 9, 0, 0, 0), (48, 15, 5, 0, 0), (16, 7, -4, 10, 15), (64, 21, 0, 0, 8)])
+def test_both_views_in_one_launch(adf, oracle, nd, wsz, md, texthr, uniq):
+    """adf_bm_compute_both_device (extension): identical to the left matcher and createRightMatcher's matcher run
+    separately (DF.cpp:417-431: views swapped, minDisparity = -(min+num)+1, texture / uniqueness tests off)."""
+    import torch
+    N, H, W = 2, 45, 330
+    pairs = [_views(500 + i + nd, H, W, shift=3 + 2 * i) for i in range(N)]
+    tl = torch.from_numpy(np.stack([p[0] for p in pairs])).cuda()
+    tr = torch.from_numpy(np.stack([p[1] for p in pairs])).cuda()
+    lm = _bm(adf, nd, wsz, md, 31, texthr, uniq)
+    dl, dr = lm.computeBoth(tl, tr)
+    torch.cuda.synchronize()
+    for i, (l, r) in enumerate(pairs):
+        assert np.array_equal(dl[i].cpu().numpy(), oracle.bm_compute(l, r, nd, wsz, md, 31, texthr, uniq))
+        assert np.array_equal(dr[i].cpu().numpy(), oracle.bm_compute(r, l, nd, wsz, -(md + nd) + 1, 31, 0, 0))
+    rm = adf.createRightMatcher(lm)
+    assert torch.equal(dr, rm.compute(tr, tl)) and torch.equal(dl, lm.compute(tl, tr))
+    one_l, one_r = lm.computeBoth(tl[0], tr[0])                      # unbatched
+    assert torch.equal(one_l, dl[0]) and torch.equal(one_r, dr[0])

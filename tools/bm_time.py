@@ -34,5 +34,16 @@ for _ in range(reps):
 e1.record(); torch.cuda.synchronize()
 ms = e0.elapsed_time(e1) / reps
 px = n * W * H
+both = None
+if len(sys.argv) <= 6:                       # the filter's configuration: also time both views in one launch
+    for _ in range(2):
+        lm.computeBoth(left, right, dl, dr)
+    torch.cuda.synchronize()
+    e0.record()
+    for _ in range(reps):
+        lm.computeBoth(left, right, dl, dr)
+    e1.record(); torch.cuda.synchronize()
+    both = e0.elapsed_time(e1) / reps
 print("matcher both views: %dx%d ndisp %d block %d, %d pairs: %.2f ms  (%.3f ms/pair, %.2f Gpx/s, %.1f G(px*disp)/s per view)" %
-      (W, H, nd, wsz, n, ms, ms / n, px / ms / 1e6, 2 * px * nd / ms / 1e6))
+      (W, H, nd, wsz, n, ms, ms / n, px / ms / 1e6, 2 * px * nd / ms / 1e6) +
+      ("" if both is None else "; one launch for both views: %.2f ms (%.3f ms/pair)" % (both, both / n)))
