@@ -108,7 +108,7 @@ def views_to_filtered(xi, view, roi, radius, n, num_disp, block):
             "matcher_ms_per_pair": round(ev[0].elapsed_time(ev[1]) / n, 4),
             "filter_ms_per_pair": round(ev[1].elapsed_time(ev[2]) / n, 4),
             "Mpixels_per_s": round(n * H * W / (ev[0].elapsed_time(ev[2]) * 1e-3) / 1e6, 1),
-            "note": "block matcher (left + right view) then filter, one call each for the batch; not part of `value`"}
+            "note": "block matcher (left + right view from one launch) then the filter, each one call for the batch; not part of `value`"}
 
 
 def main():
