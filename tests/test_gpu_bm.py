@@ -183,3 +183,18 @@ def test_both_views_in_one_launch(adf, oracle, nd, wsz, md, texthr, uniq):
     assert torch.equal(dr, rm.compute(tr, tl)) and torch.equal(dl, lm.compute(tl, tr))
     one_l, one_r = lm.computeBoth(tl[0], tr[0])                      # unbatched
     assert torch.equal(one_l, dl[0]) and torch.equal(one_r, dr[0])
+
+
+@pytest.mark.parametrize("H,W,nd,wsz,md,uniq", [(40, 7680, 512, 15, 0, 0), (36, 5000, 1024, 9, -300, 7), (33, 4099, 496, 21, 16, 0)])
+def test_wide_images_and_long_searches(adf, oracle, H, W, nd, wsz, md, uniq):
+    """Many column tiles and searches far longer than a tile (8K-wide rows, up to 1024 disparities)."""
+    import torch
+    left, right = _views(H + W, H, W, shift=37)
+    tl, tr = torch.from_numpy(left).cuda(), torch.from_numpy(right).cuda()
+    bm = _bm(adf, nd, wsz, md, 31, 0, uniq)
+    exp = oracle.bm_compute(left, right, nd, wsz, md, 31, 0, uniq)
+    assert np.array_equal(bm.compute(tl, tr).cpu().numpy(), exp)
+    if uniq == 0:
+        dl, dr = bm.computeBoth(tl, tr)
+        assert np.array_equal(dl.cpu().numpy(), exp)
+        assert np.array_equal(dr.cpu().numpy(), oracle.bm_compute(right, left, nd, wsz, -(md + nd) + 1, 31, 0, 0))
