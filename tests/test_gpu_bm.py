@@ -99,6 +99,8 @@ def test_matcher_errors(adf):
     bm = _bm(adf, 16, 9); bm.setSpeckleWindowSize(100)
     with pytest.raises(adf.AdfError):
         bm.compute(left, right)
+    with pytest.raises(adf.AdfError):                       # both-views extension: device tensors only
+        _bm(adf, 16, 9).computeBoth(left, right)
 
 
 def test_views_to_filtered_disparity_on_device(adf, oracle):
