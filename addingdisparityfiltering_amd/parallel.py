@@ -97,3 +97,136 @@ def sum_over_ranks(value, device, group=None):
     t = torch.tensor([float(value)], dtype=torch.float64, device=device)
     dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
     return float(t.item())
+
+
+def min_over_ranks(value, device, group=None):
+    """Min of a python float over ranks (all ranks agree on a pass / fail flag)."""
+    rank, world = _world(group)
+    if world == 1:
+        return float(value)
+    t = torch.tensor([float(value)], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MIN, group=group)
+    return float(t.item())
+
+
+def gather_scalars(value, device, group=None):
+    """[value of rank 0, value of rank 1, ...] on every rank: one all-reduce of a world-sized vector."""
+    rank, world = _world(group)
+    if world == 1:
+        return [float(value)]
+    t = torch.zeros(world, dtype=torch.float64, device=device)
+    t[rank] = float(value)
+    dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+    return [float(v) for v in t.tolist()]
+
+
+def gather_objects(obj, group=None):
+    """[obj of rank 0, ...] on every rank (small python objects: check reports)."""
+    rank, world = _world(group)
+    if world == 1:
+        return [obj]
+    out = [None] * world
+    dist.all_gather_object(out, obj, group=group)
+    return out
+
+
+def sub_range(n_total, rank, world, sub, n_sub):
+    """Global [start, stop) of sub-batch `sub` of `n_sub` inside the shard of `rank`."""
+    a, b = shard_range(n_total, rank, world)
+    lo, hi = shard_range(b - a, sub, n_sub)
+    return a + lo, a + hi
+
+
+def pipelined_scatter_filter_gather(full, n_total, in_shapes, in_dtypes, out_shape, out_dtype, device, process,
+                                    n_sub=4, src=0, group=None):
+    """Serving-shaped flow of SURVEY.md 8(e): the root holds the whole batch (`full` = list of input tensors of
+    shape (n_total, *in_shapes[i]); None elsewhere); every rank's shard is cut into `n_sub` sub-batches and the
+    transfers of sub-batch s+1 (root -> ranks) and s-1 (ranks -> root) are in flight while sub-batch s is filtered.
+
+    `process(*inputs_of_the_sub_batch, out_of_the_sub_batch)` filters one sub-batch (asynchronously on the
+    current stream for device tensors).  Point-to-point only: on an MI355X node every peer is one xGMI link
+    from the root, so the root's seven sends proceed on seven links at once.  Ordering on CUDA: torch's NCCL
+    work is enqueued behind what the current stream holds at that moment and `wait()` makes the current stream
+    wait for that one transfer, so issue order alone gives  scatter(s+1) || filter(s) || gather(s-1).
+
+    Returns (stats, full_out): stats = dict(total_ms, sub_batches) on every rank (max over ranks, barrier to
+    barrier), full_out = (n_total, *out_shape) on the root, None elsewhere."""
+    import time
+
+    rank, world = _world(group)
+    a, b = shard_range(n_total, rank, world)
+    n_local = b - a
+    n_sub = max(1, min(int(n_sub), max(1, n_total // max(world, 1))))      # the same on every rank
+    cuda = torch.device(device).type == "cuda"
+
+    def dsync():
+        if cuda:
+            torch.cuda.synchronize(device)
+
+    if rank == src:
+        local_in = [t[a:b] for t in full]
+        full_out = torch.empty((n_total,) + tuple(out_shape), dtype=out_dtype, device=device)
+        local_out = full_out[a:b]
+    else:
+        local_in = [torch.empty((n_local,) + tuple(s), dtype=d, device=device) for s, d in zip(in_shapes, in_dtypes)]
+        full_out = None
+        local_out = torch.empty((n_local,) + tuple(out_shape), dtype=out_dtype, device=device)
+
+    def post(ops):
+        return dist.batch_isend_irecv(ops) if ops else []
+
+    def post_scatter(s):
+        ops = []
+        if world == 1:
+            return []
+        if rank == src:
+            for peer in range(world):
+                if peer == src:
+                    continue
+                lo, hi = sub_range(n_total, peer, world, s, n_sub)
+                if hi > lo:
+                    ops += [dist.P2POp(dist.isend, t[lo:hi], peer, group) for t in full]
+        else:
+            lo, hi = sub_range(n_total, rank, world, s, n_sub)
+            if hi > lo:
+                ops += [dist.P2POp(dist.irecv, t[lo - a:hi - a], src, group) for t in local_in]
+        return post(ops)
+
+    def post_gather(s):
+        ops = []
+        if world == 1:
+            return []
+        if rank == src:
+            for peer in range(world):
+                if peer == src:
+                    continue
+                lo, hi = sub_range(n_total, peer, world, s, n_sub)
+                if hi > lo:
+                    ops.append(dist.P2POp(dist.irecv, full_out[lo:hi], peer, group))
+        else:
+            lo, hi = sub_range(n_total, rank, world, s, n_sub)
+            if hi > lo:
+                ops.append(dist.P2POp(dist.isend, local_out[lo - a:hi - a], src, group))
+        return post(ops)
+
+    dsync()
+    if world > 1:
+        dist.barrier(group)
+    t0 = time.perf_counter()
+    pending = post_scatter(0)
+    gathers = []
+    for s in range(n_sub):
+        for w in pending:
+            w.wait()
+        pending = post_scatter(s + 1) if s + 1 < n_sub else []
+        lo, hi = sub_range(n_total, rank, world, s, n_sub)
+        if hi > lo:
+            process(*[t[lo - a:hi - a] for t in local_in], local_out[lo - a:hi - a])
+        gathers += post_gather(s)
+    for w in gathers:
+        w.wait()
+    dsync()
+    if world > 1:
+        dist.barrier(group)
+    total = max_over_ranks(time.perf_counter() - t0, device if cuda else torch.device("cpu"), group)
+    return {"total_ms": round(total * 1e3, 3), "sub_batches": n_sub}, full_out

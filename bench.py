@@ -1,25 +1,35 @@
 #!/usr/bin/env python3
 """bench.py -- DisparityWLSFilter throughput on MI355X (BASELINE.json metric).
 
-    python bench.py --gpus 1 --steps K --warmup W
-    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+    python bench.py --gpus N --steps K --warmup W          (N > 1: starts its own N worker processes)
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...   (also fine)
 
 One "step" = one DisparityWLSFilter::filter call over this rank's batch of synthetic stereo pairs
 (BASELINE config 3: 64 pairs of 3840x2160 per GPU, ROI (256,0,3584,2160), 8UC3 guide, lambda 8000,
 sigma 1.5, 3 FGS iterations, LRC confidence on), inputs and outputs resident in HBM.  Pairs are
-independent, so N GPUs filter N x 64 pairs (weak scaling); RCCL is used only to scatter the batch
-from rank 0 before, and gather the filtered maps after, the timed region.
+independent, so N GPUs filter N x 64 pairs (weak scaling) with no collective on the data path; RCCL
+carries a few scalar all-reduces (max time, checksum, check flags) and, with --distribution scatter, the
+batch scatter / gather around the timed region plus an extra pipelined scatter -> filter -> gather leg.
 
 Prints ONE JSON line on rank 0 (see the driver contract in the task statement):
   value     = whole-job filtered Mpixels/s (full-frame W*H per pair), max-over-ranks time
   roofline  = dominant kernel (the Thomas-solve pass) priced in ALGORITHMIC bytes:
               (4+8R)*P bytes per launch / mean launch duration from HIP events on the launch stream
   cpu_baseline = the CPU oracle (a port of the reference path) timed on this box's host cores
+
+Launching.  Under torch.distributed.run (RANK / WORLD_SIZE in the environment) this process IS a worker.
+A plain `python bench.py --gpus N` with N > 1 becomes a launcher instead: it starts N fresh worker
+processes (RANK, LOCAL_RANK, WORLD_SIZE, MASTER_ADDR=127.0.0.1, MASTER_PORT set) BEFORE anything in it
+has touched a GPU -- the launcher never imports torch --, relays rank 0's single JSON line and exits
+non-zero if any worker does.  Nothing is ever exec'ed from a process that has initialised the GPU.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
+import tempfile
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -29,7 +39,7 @@ if ROOT not in sys.path:
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s is the measured copy ceiling
 
 
-def parse_args():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
@@ -41,202 +51,333 @@ def parse_args():
                     help="N>1: each rank builds its own contiguous shard of the batch (default: the path shards "
                          "with no data-path collective), or rank 0 builds the whole batch and scatters it / gathers "
                          "the results over RCCL point-to-point groups (outside the timed region either way)")
-    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU baseline budget (0 = skip)")
-    ap.add_argument("--no-check", action="store_true", help="skip the oracle check of pair 0")
+    ap.add_argument("--sub-batches", type=int, default=4,
+                    help="--distribution scatter: sub-batches of the extra pipelined scatter -> filter -> gather leg")
+    ap.add_argument("--cpu-seconds", type=float, default=16.0, help="CPU baseline budget (0 = skip)")
+    ap.add_argument("--no-check", action="store_true", help="skip the oracle check of the first and last pair")
     ap.add_argument("--matcher-pairs", type=int, default=4,
                     help="pairs of the extra views -> matcher -> filter leg (SURVEY 8f N4; N=1 only, 0 = skip)")
-    return ap.parse_args()
+    ap.add_argument("--dry-run", action="store_true",
+                    help="launcher / rendezvous rehearsal without a GPU: gloo, no filter call, value 0 (tests)")
+    ap.add_argument("--launch-timeout", type=float, default=1500.0, help="self-launch: seconds before workers are stopped")
+    return ap.parse_args(argv)
 
 
+# ---------------------------------------------------------------------------------------------
+# self-launch (N > 1 without torchrun)
+# ---------------------------------------------------------------------------------------------
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def launch_workers(args, argv):
+    """Start args.gpus worker processes of this script, one per GPU; relay rank 0's stdout; propagate failure.
+
+    This process stays GPU-free (no torch import, no HIP call), so starting children is an ordinary spawn, not
+    a re-exec of a process that owns a GPU context."""
+    n = args.gpus
+    env0 = dict(os.environ)
+    env0.update(WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()),
+                ADF_BENCH_WORKER="1")
+    env0.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")    # dmabuf IPC only on this pool (RCCL needs it)
+    env0.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 8) // n)))
+    cap = tempfile.TemporaryFile(mode="w+")                # rank 0's stdout = the JSON line
+    procs = []
+    for r in range(n):
+        env = dict(env0, RANK=str(r), LOCAL_RANK=str(r))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env,
+                                      stdout=cap if r == 0 else sys.stderr, stderr=sys.stderr, cwd=os.getcwd()))
+    deadline = time.time() + args.launch_timeout
+    failed = None
+    live = list(range(n))
+    while live and failed is None:
+        time.sleep(0.2)
+        for r in list(live):
+            rc = procs[r].poll()
+            if rc is None:
+                continue
+            live.remove(r)
+            if rc != 0 and failed is None:
+                failed = (r, rc)
+        if failed is None and live and time.time() > deadline:
+            failed = (live[0], 124)
+    if failed is not None:                                 # stop exactly the processes started above
+        for r in live:
+            procs[r].terminate()
+        t_end = time.time() + 15
+        for r in live:
+            try:
+                procs[r].wait(timeout=max(0.1, t_end - time.time()))
+            except subprocess.TimeoutExpired:
+                procs[r].kill()
+        sys.stderr.write("bench launcher: rank %d exited with code %d\n" % failed)
+    cap.seek(0)
+    sys.stdout.write(cap.read())
+    sys.stdout.flush()
+    return 0 if failed is None else (failed[1] if failed[1] > 0 else 1)
+
+
+# ---------------------------------------------------------------------------------------------
+# CPU baseline
+# ---------------------------------------------------------------------------------------------
 def cpu_baseline(view, dl, dr, roi, radius, seconds):
     """Time the CPU oracle like perf_disparity_wls_filter.cpp:86-90 (filter built inside the loop).
 
-    The stripe count (= thread count, DF.cpp:158) that is fastest on this host is not known in
-    advance, so a few candidates share the time budget and the best one is reported."""
+    Reported: the 1-thread rate and the rate at the fastest stripe count (= thread count, DF.cpp:158; not known
+    in advance, so a few candidates share the budget), each for the scalar evaluation order (process_row,
+    FGS.cpp:439-464) and for the order the reference's default SIMD build takes (FGS.cpp:251-437, 516-548)."""
     import oracle
 
     avail = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-    cands = sorted({t for t in (8, 16, 32, 64, avail) if t <= avail} or {1})
+    cands = [1] + sorted({t for t in (8, 16, 32, 64, 128, avail) if 1 < t <= avail})
     n = view.shape[0]
     H, W = dl.shape[1:]
-    best, tried = None, []
-    for threads in cands:
-        p = oracle.default_params(sigma_color=1.5, disc_radius=radius, threads=threads)
-        p.lambda_ = 8000.0
-        oracle.wls_filter(dl[0], view[0], dr[0], roi, p, want_conf=True)  # warm-up cycle
-        cycles, t0 = 0, time.perf_counter()
-        while True:
-            k = cycles % n
-            oracle.wls_filter(dl[k], view[k], dr[k], roi, p, want_conf=True)
-            cycles += 1
-            el = time.perf_counter() - t0
-            if el >= seconds / len(cands) or cycles >= 200:
-                break
-        rate = cycles * W * H / el / 1e6
-        tried.append("%d thr: %.1f Mpx/s (%d calls, %.1f s)" % (threads, rate, cycles, el))
-        if best is None or rate > best[0]:
-            best = (rate, threads)
+    orders = (("scalar", oracle.ORDER_SCALAR), ("ref_simd", oracle.ORDER_REF_SIMD))
+    slot = seconds / (len(cands) * len(orders))
+    best, one, tried = None, {}, []
+    for oname, order in orders:
+        for threads in cands:
+            p = oracle.default_params(sigma_color=1.5, disc_radius=radius, threads=threads, order=order)
+            p.lambda_ = 8000.0
+            if threads > 1:
+                oracle.wls_filter(dl[0], view[0], dr[0], roi, p, want_conf=True)  # warm-up cycle
+            cycles, t0 = 0, time.perf_counter()
+            while True:
+                k = cycles % n
+                oracle.wls_filter(dl[k], view[k], dr[k], roi, p, want_conf=True)
+                cycles += 1
+                el = time.perf_counter() - t0
+                if el >= slot or cycles >= 200:
+                    break
+            rate = cycles * W * H / el / 1e6
+            tried.append("%s/%d thr: %.1f" % (oname, threads, rate))
+            if threads == 1:
+                one[oname] = round(rate, 2)
+            if best is None or rate > best[0]:
+                best = (rate, threads, oname)
     return {
-        "value": round(best[0], 3), "unit": "Mpixels/s", "cores": best[1], "kind": "port",
+        "value": round(best[0], 3), "unit": "Mpixels/s", "cores": best[1], "kind": "port", "order": best[2],
+        "one_thread": one,
         "sample": "DisparityWLSFilter on %d pair(s) of %dx%d, same inputs/params as the GPU run; oracle/adf_oracle.c "
-                  "(scalar order, pthread stripes); %d logical CPUs visible; tried %s"
-                  % (n, W, H, avail, "; ".join(tried)),
+                  "(pooled pthread stripes end to end like ParallelLoopBody); %d logical CPUs visible; Mpixels/s by "
+                  "evaluation order / threads: %s" % (n, W, H, avail, "; ".join(tried)),
     }
 
 
-def views_to_filtered(xi, view, roi, radius, n, num_disp, block):
-    """Extra leg, outside the timed region and not part of `value`: the device block matcher (both views) feeding the
+def views_to_filtered(xi, view, roi, radius, n, num_disp, block, matcher="bm"):
+    """Extra leg, outside the timed region and not part of `value`: a device matcher (both views) feeding the
     filter, all stages on torch's stream, inputs resident."""
     import torch
-    left = view[:n, :, :, 0].contiguous()
+    left = view[:n, :, :, 0].contiguous() if view.dim() == 4 else view[:n].contiguous()
     right = torch.roll(left, -min(num_disp // 3, 60), 2).contiguous()
-    lm = xi.StereoBM.create(num_disp, block)
+    if matcher == "sgbm":
+        lm = xi.StereoSGBM.create(0, num_disp, block)
+        lm.setP1(24 * block * block); lm.setP2(96 * block * block)          # samples/disparity_filtering.cpp:166-170
+        lm.setMode(xi.StereoSGBM.MODE_SGBM_3WAY)
+    else:
+        lm = xi.StereoBM.create(num_disp, block)
     wls = xi.createDisparityWLSFilter(lm)                    # DF.cpp:386-414 (forces texture / uniqueness tests off)
-    rm = xi.createRightMatcher(lm)                           # DF.cpp:417-431
+    rm = xi.createRightMatcher(lm)                           # DF.cpp:417-449
     wls.setLambda(8000.0); wls.setSigmaColor(1.5)
     H, W = left.shape[1:]
     dl = torch.empty((n, H, W), dtype=torch.int16, device=left.device); dr = torch.empty_like(dl); out = torch.empty_like(dl)
     ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
     for it in range(2):                                      # first round warms the workspaces up
         ev[0].record()
-        lm.computeBoth(left, right, dl, dr)                  # = lm.compute(left, right), rm.compute(right, left)
+        if matcher == "sgbm":
+            lm.compute(left, right, dl)
+            rm.compute(right, left, dr)
+        else:
+            lm.computeBoth(left, right, dl, dr)              # = lm.compute(left, right), rm.compute(right, left)
         ev[1].record()
         wls.filter(dl, view[:n], out, dr)
         ev[2].record()
     torch.cuda.synchronize()
-    return {"pairs": n, "num_disparities": num_disp, "block_size": block, "roi": list(wls.getROI()),
+    return {"matcher": matcher, "pairs": n, "num_disparities": num_disp, "block_size": block, "roi": list(wls.getROI()),
             "matcher_ms_per_pair": round(ev[0].elapsed_time(ev[1]) / n, 4),
             "filter_ms_per_pair": round(ev[1].elapsed_time(ev[2]) / n, 4),
             "Mpixels_per_s": round(n * H * W / (ev[0].elapsed_time(ev[2]) * 1e-3) / 1e6, 1),
-            "note": "block matcher (left + right view from one launch) then the filter, each one call for the batch; not part of `value`"}
+            "note": "left + right view matcher then the filter, each one call for the batch; not part of `value`"}
 
 
-def main():
-    args = parse_args()
+def check_pairs(f, out, view, dl, dr, roi, radius, solver, which, threads):
+    """Pairs `which` of this rank's batch against the CPU oracle (the checker, never the thing measured)."""
     import numpy as np
+    import oracle
+    p = oracle.default_params(sigma_color=1.5, disc_radius=radius, threads=threads)
+    p.lambda_ = 8000.0
+    res, ok = [], True
+    for k in which:
+        exp, exp_conf = oracle.wls_filter(dl[k].cpu().numpy(), view[k].cpu().numpy(), dr[k].cpu().numpy(), roi, p)
+        got = out[k].cpu().numpy().astype(np.int64)
+        conf_ok = bool(np.array_equal(f.getConfidenceMap(k).cpu().numpy(), exp_conf))
+        diff = np.abs(got - exp)
+        res.append({"pair": int(k), "confidence_bit_exact": conf_ok, "disparity_max_abs_lsb": int(diff.max()),
+                    "disparity_mean_abs_lsb": float(diff.mean())})
+        ok = ok and conf_ok and (diff.max() == 0 if solver == "exact" else (diff.max() <= 1 and diff.mean() <= 1 / 256))
+    return ok, res
+
+
+def worker(args):
+    # Libraries under us write to stdout (gloo's connection banner, RCCL with NCCL_DEBUG set): the one JSON line
+    # goes to a private copy of the original stdout and everything else any library prints lands on stderr.
+    sys.stdout.flush()
+    json_out = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
+
     import torch
     import torch.distributed as dist
 
-    import addingdisparityfiltering_amd as adf
     from addingdisparityfiltering_amd import parallel, synthetic
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if args.gpus > 1 or world > 1:
-        if world != args.gpus:
-            raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run" % (args.gpus, world))
+    if world > 1 and world != args.gpus:
+        sys.stderr.write("bench: --gpus %d but WORLD_SIZE=%d: using the launched world size\n" % (args.gpus, world))
+    if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-    if not torch.cuda.is_available():
+    dry = args.dry_run
+    if not dry and not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
     # ADF_BENCH_BACKEND=gloo is a rehearsal mode for one-GPU boxes: the ranks share the visible GPUs
-    # (rank r uses device r % device_count) and the two scalar all-reduces run on CPU tensors, so the whole
+    # (rank r uses device r % device_count) and the scalar all-reduces run on CPU tensors, so the whole
     # N > 1 flow executes except RCCL itself.  The driver's runs use the default, nccl (= RCCL).
-    backend = os.environ.get("ADF_BENCH_BACKEND", "nccl")
-    dev_index = local_rank if backend == "nccl" else local_rank % max(1, torch.cuda.device_count())
-    torch.cuda.set_device(dev_index)
-    dev = torch.device("cuda", dev_index)
+    backend = "gloo" if dry else os.environ.get("ADF_BENCH_BACKEND", "nccl")
+    if dry:
+        dev = torch.device("cpu")
+    else:
+        dev_index = local_rank if backend == "nccl" else local_rank % max(1, torch.cuda.device_count())
+        torch.cuda.set_device(dev_index)
+        dev = torch.device("cuda", dev_index)
     coll_dev = dev if backend == "nccl" else torch.device("cpu")
     if world > 1:
         if backend == "nccl":
             dist.init_process_group(backend="nccl", device_id=dev)
         else:
-            if args.distribution == "scatter":
+            if args.distribution == "scatter" and not dry:
                 raise SystemExit("the scatter distribution moves device tensors: it needs the nccl backend")
             dist.init_process_group(backend=backend)
+        assert dist.get_world_size() == world and dist.get_rank() == rank
+
+    def sync():
+        if not dry:
+            torch.cuda.synchronize()
 
     cfg = synthetic.CONFIGS[args.config]
     W, H, roi, ch, radius = cfg["W"], cfg["H"], cfg["roi"], cfg["channels"], cfg["radius"]
     pairs = args.pairs
     n_total = pairs * world
+    vshape = (H, W, ch) if ch > 1 else (H, W)
 
-    # ---- inputs, resident in HBM before the timed region ----
+    adf = f = view = dl = dr = None
+    full = [None, None, None]
     scatter_ms = None
-    base_seed = synthetic.seed_for(args.config, 0)
-    if world > 1 and args.distribution == "scatter":
-        full = [None, None, None]
-        if rank == 0:
-            full = list(synthetic.make_artificial_batch_torch(n_total, W, H, ch, base_seed, cfg["rect_disparity"], dev))
-        torch.cuda.synchronize(); dist.barrier()
-        t0 = time.perf_counter()
-        vshape = (H, W, ch) if ch > 1 else (H, W)
-        view = parallel.scatter_batch(full[0], n_total, vshape, torch.uint8, dev)
-        dl = parallel.scatter_batch(full[1], n_total, (H, W), torch.int16, dev)
-        dr = parallel.scatter_batch(full[2], n_total, (H, W), torch.int16, dev)
-        torch.cuda.synchronize(); dist.barrier()
-        scatter_ms = (time.perf_counter() - t0) * 1e3
-        view, dl, dr = view.contiguous().clone(), dl.contiguous().clone(), dr.contiguous().clone()
-        del full
-        torch.cuda.empty_cache()
+    if dry:
+        out = torch.full((pairs, 4, 4), rank + 1, dtype=torch.int16)
     else:
-        view, dl, dr = synthetic.make_artificial_batch_torch(pairs, W, H, ch, base_seed + rank * pairs,
-                                                             cfg["rect_disparity"], dev)
-    out = torch.empty((pairs, H, W), dtype=torch.int16, device=dev)
+        import addingdisparityfiltering_amd as adf
+        # ---- inputs, resident in HBM before the timed region ----
+        base_seed = synthetic.seed_for(args.config, 0)
+        if world > 1 and args.distribution == "scatter":
+            if rank == 0:
+                full = list(synthetic.make_artificial_batch_torch(n_total, W, H, ch, base_seed, cfg["rect_disparity"], dev))
+            sync(); dist.barrier()
+            t0 = time.perf_counter()
+            view = parallel.scatter_batch(full[0], n_total, vshape, torch.uint8, dev)
+            dl = parallel.scatter_batch(full[1], n_total, (H, W), torch.int16, dev)
+            dr = parallel.scatter_batch(full[2], n_total, (H, W), torch.int16, dev)
+            sync(); dist.barrier()
+            scatter_ms = (time.perf_counter() - t0) * 1e3
+            view, dl, dr = view.contiguous().clone(), dl.contiguous().clone(), dr.contiguous().clone()
+        else:
+            view, dl, dr = synthetic.make_artificial_batch_torch(pairs, W, H, ch, base_seed + rank * pairs,
+                                                                 cfg["rect_disparity"], dev)
+        out = torch.empty((pairs, H, W), dtype=torch.int16, device=dev)
 
-    f = adf.createDisparityWLSFilterGeneric(True)
-    f.setLambda(8000.0)
-    f.setSigmaColor(1.5)
-    f.setDepthDiscontinuityRadius(radius)
-    f.setSolver(adf.SOLVER_WAVE if args.solver == "wave" else adf.SOLVER_EXACT)
+        f = adf.createDisparityWLSFilterGeneric(True)
+        f.setLambda(8000.0)
+        f.setSigmaColor(1.5)
+        f.setDepthDiscontinuityRadius(radius)
+        f.setSolver(adf.SOLVER_WAVE if args.solver == "wave" else adf.SOLVER_EXACT)
+        f.enableProfiling(True)   # also during warm-up, so that the event pool exists before the timed region
 
-    f.enableProfiling(True)   # also during warm-up, so that the event pool exists before the timed region
+    def step():
+        if dry:
+            time.sleep(0.01)
+        else:
+            f.filter(dl, view, out, dr, roi)
+
     for _ in range(max(args.warmup, 0)):
-        f.filter(dl, view, out, dr, roi)
-    torch.cuda.synchronize()
+        step()
+    sync()
 
-    # ---- correctness of what is being timed: pair 0 of rank 0 against the CPU oracle ----
+    # ---- correctness of what is being timed: first and last pair of EVERY rank against the CPU oracle ----
     checked = None
-    if rank == 0 and not args.no_check:
-        import oracle
+    if not args.no_check and not dry:
         if args.warmup <= 0:
-            f.filter(dl, view, out, dr, roi); torch.cuda.synchronize()
-        p = oracle.default_params(sigma_color=1.5, disc_radius=radius,
-                                  threads=len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else 8)
-        p.lambda_ = 8000.0
-        exp, exp_conf = oracle.wls_filter(dl[0].cpu().numpy(), view[0].cpu().numpy(), dr[0].cpu().numpy(), roi, p)
-        got = out[0].cpu().numpy().astype(np.int64)
-        conf_ok = bool(np.array_equal(f.getConfidenceMap(0).cpu().numpy(), exp_conf))
-        diff = np.abs(got - exp)
-        checked = {"pair": 0, "confidence_bit_exact": conf_ok, "disparity_max_abs_lsb": int(diff.max()),
-                   "disparity_mean_abs_lsb": float(diff.mean())}
-        ok = conf_ok and (diff.max() == 0 if args.solver == "exact" else (diff.max() <= 1 and diff.mean() <= 1 / 256))
+            step(); sync()
+        cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else 8
+        ok, checked = check_pairs(f, out, view, dl, dr, roi, radius, args.solver,
+                                  sorted({0, pairs - 1}), max(1, cores // world))
+        all_ok = parallel.min_over_ranks(1.0 if ok else 0.0, coll_dev) > 0.5
         if not ok:
-            raise SystemExit("bench: GPU result differs from the oracle: %s" % checked)
+            sys.stderr.write("bench: rank %d: GPU result differs from the oracle: %s\n" % (rank, checked))
+        if not all_ok:
+            if world > 1:
+                dist.destroy_process_group()
+            raise SystemExit(3)
 
     # ---- timed region: exactly K steps, barrier + synchronize on both sides ----
-    f.enableProfiling(True)
+    if f is not None:
+        f.enableProfiling(True)
     if world > 1:
         dist.barrier()
-    torch.cuda.synchronize()
+    sync()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        f.filter(dl, view, out, dr, roi)
-    torch.cuda.synchronize()
+        step()
+    sync()
+    my_elapsed = time.perf_counter() - t0
     if world > 1:
         dist.barrier()
     elapsed = time.perf_counter() - t0
     elapsed = parallel.max_over_ranks(elapsed, coll_dev)
-    prof = f.readProfile()
-    f.enableProfiling(False)
+    per_rank_ms = [round(v / args.steps * 1e3, 3) for v in parallel.gather_scalars(my_elapsed, coll_dev)]
+    prof = f.readProfile() if f is not None else {}
+    if f is not None:
+        f.enableProfiling(False)
 
-    # ---- gather the filtered maps (outside the timed region) ----
-    gather_ms = None
-    if world > 1 and args.distribution == "scatter":
-        torch.cuda.synchronize(); dist.barrier()
+    # ---- gather the filtered maps (outside the timed region), then the pipelined serving-shaped leg ----
+    gather_ms, pipelined = None, None
+    if world > 1 and args.distribution == "scatter" and not dry:
+        sync(); dist.barrier()
         t1 = time.perf_counter()
         full_out = parallel.gather_batch(out, n_total)
-        torch.cuda.synchronize(); dist.barrier()
+        sync(); dist.barrier()
         gather_ms = (time.perf_counter() - t1) * 1e3
         del full_out
+        pipelined, _full_out = parallel.pipelined_scatter_filter_gather(
+            full if rank == 0 else None, n_total, [vshape, (H, W), (H, W)], [torch.uint8, torch.int16, torch.int16],
+            (H, W), torch.int16, dev, lambda v, a, b, o: f.filter(a, v, o, b, roi), args.sub_batches)
+        del _full_out
+        pipelined["resident_compute_ms"] = round(elapsed / args.steps * 1e3, 3)
+        pipelined["blocking_scatter_plus_gather_ms"] = round(scatter_ms + gather_ms, 3)
+        pipelined["exposed_transfer_ms"] = round(pipelined["total_ms"] - pipelined["resident_compute_ms"], 3)
+        pipelined["hidden_transfer_ms"] = round(max(0.0, scatter_ms + gather_ms - pipelined["exposed_transfer_ms"]), 3)
+    full = None
     checksum = parallel.sum_over_ranks(float(out.to(torch.int64).sum().item()), coll_dev)
+    checked_all = parallel.gather_objects(checked) if (world > 1 and checked is not None) else checked
 
     if rank != 0:
         if world > 1:
             dist.destroy_process_group()
         return
 
-    mpx = n_total * W * H * args.steps / elapsed / 1e6
+    mpx = 0.0 if dry else n_total * W * H * args.steps / elapsed / 1e6
     P = roi[2] * roi[3]
     alg_per_launch = 20.0 * P * pairs          # (4 + 8R) bytes per ROI pixel, R = 2 (SURVEY 8d)
 
@@ -263,17 +404,25 @@ def main():
         dom_classes = [max(("pass_h", "pass_v"), key=lambda k: prof.get(k, {}).get("total_ms", 0.0))]
     launches, avg_ms = pass_stats(dom_classes)
     achieved = alg_per_launch / (avg_ms * 1e-3) / 1e9 if launches else 0.0
-    traffic = None
+    # HBM traffic per launch is NOT measured by this run (PMC counters need their own rocprofv3 passes): it is the
+    # committed figure of profiles/pmc_traffic.json (bytes per pair x pairs); its provenance rides along so that a
+    # figure older than the kernels is visible
+    traffic, traffic_src = None, None
     tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     if os.path.exists(tpath):
         try:
-            t = json.load(open(tpath)).get("%s_cfg%d" % (args.solver, args.config), {})
+            tj = json.load(open(tpath))
+            t = tj.get("%s_cfg%d" % (args.solver, args.config), {})
             per_pair = t.get(names[dom_classes[0]], {}).get("bytes_per_pair")
             traffic = None if per_pair is None else per_pair * pairs
+            traffic_src = {"file": "profiles/pmc_traffic.json", "collected": tj.get("_collected"),
+                           "kernel_sources_sha16": tj.get("_kernel_sources_sha16"),
+                           "kernel_sources_sha16_now": _kernel_sources_sha16(), "method": tj.get("_method")}
         except Exception:
             traffic = None
     roofline = {"bound": "hbm", "kernel": names[dom_classes[0]], "achieved": round(achieved, 1),
                 "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                "traffic_source": traffic_src,
                 "launches": launches, "avg_launch_ms": round(avg_ms, 4), "alg_bytes_per_launch": alg_per_launch}
     for name in ("pass_h", "pass_v"):
         if name in prof and prof[name]["launches"]:
@@ -289,18 +438,22 @@ def main():
                    "moved_GBs": round(v["moved_bytes"] / max(v["total_ms"], 1e-9) / 1e6, 1)} for k, v in prof.items()}
 
     cpu = None
-    if world == 1 and args.cpu_seconds > 0:
+    if world == 1 and args.cpu_seconds > 0 and not dry:
         ncpu = min(pairs, 2)
         cpu = cpu_baseline(view[:ncpu].cpu().numpy(), dl[:ncpu].cpu().numpy(), dr[:ncpu].cpu().numpy(), roi, radius,
                            args.cpu_seconds)
 
     pipeline = None
-    if world == 1 and args.matcher_pairs > 0:
-        try:
-            nd = max(16, (roi[0] + 15) // 16 * 16)           # the config's ROI x is its numDisparities
-            pipeline = views_to_filtered(adf, view, roi, radius, min(args.matcher_pairs, pairs), min(nd, 256), 15)
-        except Exception as e:                               # the extra leg must never cost the bench line
-            pipeline = {"error": str(e)}
+    if world == 1 and args.matcher_pairs > 0 and not dry:
+        nd = max(16, (roi[0] + 15) // 16 * 16)               # the config's ROI x is its numDisparities
+        pipeline = {}
+        for m, blk in (("bm", 15), ("sgbm", 3)):
+            if m == "sgbm" and not hasattr(adf.StereoSGBM, "MODE_SGBM_3WAY"):
+                continue
+            try:
+                pipeline[m] = views_to_filtered(adf, view, roi, radius, min(args.matcher_pairs, pairs), min(nd, 256), blk, m)
+            except Exception as e:                           # the extra leg must never cost the bench line
+                pipeline[m] = {"error": str(e)}
 
     F = W * H
     b_alg_pair = 10.0 * F + (ch + 8 + 120) * P  # I/O + weights + 6 passes
@@ -316,17 +469,45 @@ def main():
                    "parallelism": "batch-sharded x%d" % world},
         "roofline": roofline, "cpu_baseline": cpu,
         "whole_call_alg_GBs": round(b_alg_pair * n_total * args.steps / elapsed / 1e9, 1),
-        "kernels": kernels, "checked": checked, "checksum": checksum,
+        "kernels": kernels, "checked": checked_all, "checksum": checksum,
+        "world_size": world, "backend": backend if world > 1 else None, "per_rank_ms_per_step": per_rank_ms,
+        "launcher": "self" if os.environ.get("ADF_BENCH_WORKER") else ("torchrun" if world > 1 else "single"),
         "scatter_ms": None if scatter_ms is None else round(scatter_ms, 2),
         "gather_ms": None if gather_ms is None else round(gather_ms, 2),
-        "workspace_GB": round(f.workspaceBytes() / 1e9, 2),
+        "pipelined_scatter_filter_gather": pipelined,
+        "workspace_GB": None if f is None else round(f.workspaceBytes() / 1e9, 2),
         "views_to_filtered": pipeline,
     }
+    if dry:
+        line["dry_run"] = True
     if cpu:
         line["speedup_vs_cpu"] = round(mpx / cpu["value"], 1)
-    print(json.dumps(line), flush=True)
+    json_out.write(json.dumps(line) + "\n")
+    json_out.flush()
     if world > 1:
         dist.destroy_process_group()
+
+
+def _kernel_sources_sha16():
+    """First 16 hex digits of the SHA-256 over the HIP sources: lets a reader see whether profiles/pmc_traffic.json
+    (which records the same digest when it is collected) was measured on the kernels that just ran."""
+    import hashlib
+    d = os.path.join(ROOT, "addingdisparityfiltering_amd", "csrc")
+    h = hashlib.sha256()
+    for name in sorted(os.listdir(d)):
+        if name.endswith((".hip", ".h")):
+            h.update(name.encode())
+            h.update(open(os.path.join(d, name), "rb").read())
+    return h.hexdigest()[:16]
+
+
+def main():
+    argv = sys.argv[1:]
+    args = parse_args(argv)
+    under_launcher = "RANK" in os.environ and int(os.environ.get("WORLD_SIZE", "1")) > 1
+    if args.gpus > 1 and not under_launcher:
+        sys.exit(launch_workers(args, argv))
+    worker(args)
 
 
 if __name__ == "__main__":

@@ -88,6 +88,7 @@ def lib():
         L.adf_oracle_bm_prefilter_xsobel.argtypes = [vp, pd, i, i, i, vp]
         L.adf_oracle_bm_compute.argtypes = [C.POINTER(BMParams), vp, pd, vp, pd, i, i, vp, pd]
         L.adf_oracle_bm_compute.restype = i
+        L.adf_oracle_set_refsimd_rowwise.argtypes = [i]
         L.adf_oracle_sat16.argtypes = [f]
         L.adf_oracle_sat16.restype = C.c_int16
         _lib = L
@@ -209,6 +210,11 @@ def wls_filter(dispL, guide, dispR, roi, params=None, want_conf=True):
     if rc:
         raise ValueError("adf_oracle_wls_filter rc=%d" % rc)
     return out, conf
+
+
+def set_refsimd_rowwise(on):
+    """Test hook: run ORDER_REF_SIMD as its scalar emulation instead of the 128-bit vector code."""
+    lib().adf_oracle_set_refsimd_rowwise(int(bool(on)))
 
 
 def sat16(v):

@@ -33,12 +33,43 @@
 /* (FGS.cpp:468-469, :486-487, DF.cpp:316-317).                         */
 /* ------------------------------------------------------------------ */
 typedef void (*stripe_fn)(int stripe, int nstripes, void* ctx);
-typedef struct { stripe_fn fn; int stripe, nstripes; void* ctx; } stripe_job;
 
-static void* stripe_trampoline(void* arg)
+/* A persistent pool like the one behind cv::parallel_for_: workers are created once (up to the
+ * largest stripe count asked for, minus the calling thread) and pick stripe indices off a shared
+ * counter; the caller works too and returns when every stripe is done.  One region at a time. */
+static struct {
+    pthread_mutex_t mu; pthread_cond_t work, done;
+    pthread_t* th; int nthreads;
+    stripe_fn fn; void* ctx; int nstripes, next, running; unsigned long gen;
+} g_pool = { PTHREAD_MUTEX_INITIALIZER, PTHREAD_COND_INITIALIZER, PTHREAD_COND_INITIALIZER,
+             NULL, 0, NULL, NULL, 0, 0, 0, 0 };
+static pthread_mutex_t g_region = PTHREAD_MUTEX_INITIALIZER;
+
+static void pool_drain_locked(void)
 {
-    stripe_job* j = (stripe_job*)arg;
-    j->fn(j->stripe, j->nstripes, j->ctx);
+    /* called with g_pool.mu held: run stripes until none is left */
+    while (g_pool.next < g_pool.nstripes) {
+        int s = g_pool.next++;
+        stripe_fn fn = g_pool.fn; void* ctx = g_pool.ctx; int n = g_pool.nstripes;
+        g_pool.running++;
+        pthread_mutex_unlock(&g_pool.mu);
+        fn(s, n, ctx);
+        pthread_mutex_lock(&g_pool.mu);
+        g_pool.running--;
+    }
+}
+
+static void* pool_worker(void* arg)
+{
+    (void)arg;
+    unsigned long seen = 0;
+    pthread_mutex_lock(&g_pool.mu);
+    for (;;) {
+        while (g_pool.gen == seen) pthread_cond_wait(&g_pool.work, &g_pool.mu);
+        seen = g_pool.gen;
+        pool_drain_locked();
+        if (g_pool.running == 0) pthread_cond_signal(&g_pool.done);
+    }
     return NULL;
 }
 
@@ -46,19 +77,30 @@ static void parallel_stripes(int nstripes, stripe_fn fn, void* ctx)
 {
     if (nstripes < 1) nstripes = 1;
     if (nstripes == 1) { fn(0, 1, ctx); return; }
-    pthread_t* th = (pthread_t*)malloc(sizeof(pthread_t) * (size_t)nstripes);
-    stripe_job* jobs = (stripe_job*)malloc(sizeof(stripe_job) * (size_t)nstripes);
-    char* started = (char*)calloc((size_t)nstripes, 1);
-    for (int s = 1; s < nstripes; s++) {
-        jobs[s].fn = fn; jobs[s].stripe = s; jobs[s].nstripes = nstripes; jobs[s].ctx = ctx;
-        started[s] = pthread_create(&th[s], NULL, stripe_trampoline, &jobs[s]) == 0;
+    pthread_mutex_lock(&g_region);
+    pthread_mutex_lock(&g_pool.mu);
+    if (g_pool.nthreads < nstripes - 1) {           /* grow the pool (threads live until exit) */
+        pthread_t* th = (pthread_t*)realloc(g_pool.th, sizeof(pthread_t) * (size_t)(nstripes - 1));
+        if (th) {
+            g_pool.th = th;
+            while (g_pool.nthreads < nstripes - 1) {
+                pthread_attr_t at;
+                pthread_attr_init(&at);
+                pthread_attr_setdetachstate(&at, PTHREAD_CREATE_DETACHED);
+                int rc = pthread_create(&g_pool.th[g_pool.nthreads], &at, pool_worker, NULL);
+                pthread_attr_destroy(&at);
+                if (rc != 0) break;                 /* fewer workers: the stripes still all run */
+                g_pool.nthreads++;
+            }
+        }
     }
-    fn(0, nstripes, ctx);
-    for (int s = 1; s < nstripes; s++) {
-        if (started[s]) pthread_join(th[s], NULL);
-        else fn(s, nstripes, ctx); /* thread creation failed: run inline */
-    }
-    free(started); free(jobs); free(th);
+    g_pool.fn = fn; g_pool.ctx = ctx; g_pool.nstripes = nstripes; g_pool.next = 0; g_pool.running = 0;
+    g_pool.gen++;
+    pthread_cond_broadcast(&g_pool.work);
+    pool_drain_locked();
+    while (g_pool.running > 0) pthread_cond_wait(&g_pool.done, &g_pool.mu);
+    pthread_mutex_unlock(&g_pool.mu);
+    pthread_mutex_unlock(&g_region);
 }
 
 static inline int imin(int a, int b) { return a < b ? a : b; }
@@ -107,6 +149,16 @@ void adf_oracle_lut(float sigma, float* lut)
 {
     for (int i = 0; i < ADF_LUT_LEVELS; i++)
         lut[i] = -expf(-sqrtf((float)i) / sigma);
+}
+
+/* the same table filled by stripes, FGS.cpp:154 (parallel_for_ over ComputeLUT_ParBody, :663-675) */
+typedef struct { float sigma; float* lut; } lut_ctx;
+static void lut_stripe(int s, int n, void* vctx)
+{
+    lut_ctx* c = (lut_ctx*)vctx;
+    int sz = stripe_size(ADF_LUT_LEVELS, n);
+    int start = imin(s * sz, ADF_LUT_LEVELS), end = imin((s + 1) * sz, ADF_LUT_LEVELS);
+    for (int i = start; i < end; i++) c->lut[i] = -expf(-sqrtf((float)i) / c->sigma);
 }
 
 /* ------------------------------------------------------------------ */
@@ -216,6 +268,81 @@ static void hrow_refsimd(float* u, const float* C, float* D, int w, float lambda
         u[j] = u[j] - D[j] * u[j + 1];
 }
 
+/* The same block the way the reference's default build runs it: four rows at a time on 128-bit vectors,
+ * 4x4 tiles transposed on the way in and out (FGS.cpp:295-351, 389-424).  Plain SSE2-class code through
+ * gcc's vector extensions; lane r holds row r, and every lane performs exactly the operations of
+ * hrow_refsimd in the same order, so the two produce the same bits (tests/test_oracle.py checks it). */
+typedef float v4 __attribute__((vector_size(16)));
+typedef int v4i __attribute__((vector_size(16)));
+static inline v4 ld4(const float* p) { v4 v; memcpy(&v, p, sizeof v); return v; }
+static inline void st4(float* p, v4 v) { memcpy(p, &v, sizeof v); }
+#define TRANSPOSE4(a, b, c, d)                                        \
+    do {                                                              \
+        v4 t0 = __builtin_shuffle(a, b, (v4i){0, 4, 1, 5});           \
+        v4 t1 = __builtin_shuffle(c, d, (v4i){0, 4, 1, 5});           \
+        v4 t2 = __builtin_shuffle(a, b, (v4i){2, 6, 3, 7});           \
+        v4 t3 = __builtin_shuffle(c, d, (v4i){2, 6, 3, 7});           \
+        a = __builtin_shuffle(t0, t1, (v4i){0, 1, 4, 5});             \
+        b = __builtin_shuffle(t0, t1, (v4i){2, 3, 6, 7});             \
+        c = __builtin_shuffle(t2, t3, (v4i){0, 1, 4, 5});             \
+        d = __builtin_shuffle(t2, t3, (v4i){2, 3, 6, 7});             \
+    } while (0)
+
+static void hblock4_refsimd(float* u, const float* C, float* D, int w, float lambda)
+{
+    /* u, C, D point at the first of four consecutive rows of pitch w */
+    const size_t P = (size_t)w;
+    const v4 one = {1.0f, 1.0f, 1.0f, 1.0f}, lam = {lambda, lambda, lambda, lambda};
+    v4 cp, Dp, up;
+    for (int r = 0; r < 4; r++) {                    /* FGS.cpp:278-290: first column, scalar */
+        float c0 = lambda * C[r * P];
+        D[r * P] = c0 / (1 - c0);
+        u[r * P] = u[r * P] / (1 - c0);
+        cp[r] = c0; Dp[r] = D[r * P]; up[r] = u[r * P];
+    }
+    int j = 1;
+    for (; j < w - 3; j += 4) {                      /* FGS.cpp:295-351 */
+        v4 c0 = ld4(C + j), c1 = ld4(C + P + j), c2 = ld4(C + 2 * P + j), c3 = ld4(C + 3 * P + j);
+        v4 u0 = ld4(u + j), u1 = ld4(u + P + j), u2 = ld4(u + 2 * P + j), u3 = ld4(u + 3 * P + j);
+        TRANSPOSE4(c0, c1, c2, c3);                  /* now c_k = column j+k of the four rows */
+        TRANSPOSE4(u0, u1, u2, u3);
+        v4 cc[4] = {c0 * lam, c1 * lam, c2 * lam, c3 * lam};
+        v4 uu[4] = {u0, u1, u2, u3}, dd[4];
+        for (int k = 0; k < 4; k++) {                /* PROC4, FGS.cpp:305-314 */
+            v4 aux0 = Dp * cp;
+            v4 aux1 = cc[k] + cp;
+            aux1 = one - aux1;
+            aux0 = aux1 - aux0;
+            dd[k] = cc[k] / aux0;
+            aux1 = up * cp;
+            aux1 = uu[k] - aux1;
+            uu[k] = aux1 / aux0;
+            cp = cc[k]; Dp = dd[k]; up = uu[k];
+        }
+        v4 d0 = dd[0], d1 = dd[1], d2 = dd[2], d3 = dd[3];
+        u0 = uu[0]; u1 = uu[1]; u2 = uu[2]; u3 = uu[3];
+        TRANSPOSE4(d0, d1, d2, d3);
+        TRANSPOSE4(u0, u1, u2, u3);
+        st4(D + j, d0); st4(D + P + j, d1); st4(D + 2 * P + j, d2); st4(D + 3 * P + j, d3);
+        st4(u + j, u0); st4(u + P + j, u1); st4(u + 2 * P + j, u2); st4(u + 3 * P + j, u3);
+    }
+    for (int r = 0; r < 4; r++) {                    /* FGS.cpp:357-383: scalar tail + backward sweep */
+        float* ur = u + r * P; const float* Cr = C + r * P; float* Dr = D + r * P;
+        for (int k = j; k < w; k++) {
+            float cprev = lambda * Cr[k - 1];
+            float ccur = lambda * Cr[k];
+            float den = (1 - cprev - ccur) - Dr[k - 1] * cprev;
+            Dr[k] = ccur / den;
+            ur[k] = (ur[k] - ur[k - 1] * cprev) / den;
+        }
+        for (int k = w - 2; k >= 0; k--) ur[k] = ur[k] - Dr[k] * ur[k + 1];
+    }
+}
+
+/* test hook: 1 = run the reference-SIMD order one row at a time (the scalar emulation) */
+static int g_refsimd_rowwise = 0;
+void adf_oracle_set_refsimd_rowwise(int on) { g_refsimd_rowwise = on; }
+
 static void hpass_stripe(int s, int n, void* vctx)
 {
     pass_ctx* c = (pass_ctx*)vctx;
@@ -223,10 +350,14 @@ static void hpass_stripe(int s, int n, void* vctx)
     int start = imin(s * sz, c->h), end = imin((s + 1) * sz, c->h);
     int i = start;
     if (c->order == ADF_ORDER_REF_SIMD) /* FGS.cpp:472-473: 4-row blocks from the stripe start */
-        for (; i < end - 3; i += 4)
-            for (int k = 0; k < 4; k++)
-                hrow_refsimd(c->cur + (size_t)(i + k) * c->w, c->C + (size_t)(i + k) * c->w,
-                             c->D + (size_t)(i + k) * c->w, c->w, c->lambda);
+        for (; i < end - 3; i += 4) {
+            if (c->order == ADF_ORDER_REF_SIMD && c->w >= 2 && !g_refsimd_rowwise)
+                hblock4_refsimd(c->cur + (size_t)i * c->w, c->C + (size_t)i * c->w, c->D + (size_t)i * c->w, c->w, c->lambda);
+            else
+                for (int k = 0; k < 4; k++)
+                    hrow_refsimd(c->cur + (size_t)(i + k) * c->w, c->C + (size_t)(i + k) * c->w,
+                                 c->D + (size_t)(i + k) * c->w, c->w, c->lambda);
+        }
     for (; i < end; i++)                /* FGS.cpp:474-475 */
         hrow_scalar(c->cur + (size_t)i * c->w, c->C + (size_t)i * c->w,
                     c->D + (size_t)i * c->w, c->w, c->lambda);
@@ -263,6 +394,20 @@ static void vpass_stripe(int s, int n, void* vctx)
         float* Dr = c->D + (size_t)i * w;       const float* Dp = Dr - w;
         float* ur = c->cur + (size_t)i * w;     const float* up = ur - w;
         int j = start;
+        if (!g_refsimd_rowwise)
+            for (; j + 3 < end4; j += 4) {       /* :516-547 on 128-bit vectors */
+                const v4 one = {1.0f, 1.0f, 1.0f, 1.0f}, lam = {lambda, lambda, lambda, lambda};
+                v4 cp = ld4(Cp + j) * lam;
+                v4 cc = ld4(Cr + j) * lam;
+                v4 a = ld4(Dp + j) * cp;
+                v4 b = cp + cc;
+                b = b + a;
+                a = one - b;
+                st4(Dr + j, cc / a);
+                v4 cm = ld4(up + j) * cp;
+                v4 d = ld4(ur + j) - cm;
+                st4(ur + j, d / a);
+            }
         for (; j < end4; j++) {                  /* :524-546 */
             float cp = lambda * Cp[j];
             float cc = lambda * Cr[j];
@@ -314,7 +459,7 @@ int adf_oracle_fgs_planes(const uint8_t* guide, ptrdiff_t stride, int ch, int w,
     float* cvert = (float*)malloc(sizeof(float) * n);
     float* interD = (float*)malloc(sizeof(float) * n);
     if (!lut || !chor || !cvert || !interD) { free(lut); free(chor); free(cvert); free(interD); return 4; }
-    adf_oracle_lut((float)sigma_color, lut);            /* FGS.cpp:145,154 */
+    { lut_ctx lc = { (float)sigma_color, lut }; parallel_stripes(threads, lut_stripe, &lc); } /* FGS.cpp:145,154 */
     adf_oracle_weights(guide, stride, ch, w, h, lut, chor, cvert, threads);
     for (int p = 0; p < nplanes; p++) {
         float lam = (float)lambda;                      /* FGS.cpp:146,202 */
@@ -361,6 +506,62 @@ int adf_oracle_fgs_filter(const uint8_t* guide, ptrdiff_t gstride, int gch, int 
             }
     free(planes);
     return rc;
+}
+
+/* ------------------------------------------------------------------ */
+/* Row-wise elementwise sweeps of DisparityWLSFilterImpl::filter (fill,  */
+/* prologue, epilogue).  The reference runs them as whole-Mat operations */
+/* (Scalar assignment, convertTo, mul: DF.cpp:284-296), which OpenCV     */
+/* parallelises internally; here they are striped over rows like the     */
+/* rest so that the port scales end to end.                              */
+/* ------------------------------------------------------------------ */
+enum { ROWS_ZERO_F32, ROWS_FILL_I16, ROWS_PROLOGUE, ROWS_EPILOGUE };
+typedef struct {
+    int op, rows, cols;
+    float* f0;                       /* ZERO: plane; PROLOGUE/EPILOGUE: u0 plane (cols pitch) */
+    float* f1;                       /* PROLOGUE/EPILOGUE: u1 plane */
+    int16_t fill;
+    int16_t* i16; ptrdiff_t i16_stride;          /* FILL / EPILOGUE destination (already offset to the ROI) */
+    const int16_t* disp; const float* conf;      /* PROLOGUE sources (already offset to the ROI) */
+    ptrdiff_t disp_stride; int conf_pitch;
+    int unused0, unused1;
+} rows_ctx;
+
+static void rows_stripe(int s, int n, void* vctx)
+{
+    rows_ctx* c = (rows_ctx*)vctx;
+    int sz = stripe_size(c->rows, n);
+    int start = imin(s * sz, c->rows), end = imin((s + 1) * sz, c->rows);
+    for (int i = start; i < end; i++) {
+        switch (c->op) {
+        case ROWS_ZERO_F32:
+            memset(c->f0 + (size_t)i * c->cols, 0, sizeof(float) * (size_t)c->cols);
+            break;
+        case ROWS_FILL_I16: {
+            int16_t* o = (int16_t*)((char*)c->i16 + (ptrdiff_t)i * c->i16_stride);
+            for (int j = 0; j < c->cols; j++) o[j] = c->fill;
+            break;
+        }
+        case ROWS_PROLOGUE: {                     /* DF.cpp:286-290 */
+            const int16_t* d = (const int16_t*)((const char*)c->disp + (ptrdiff_t)i * c->disp_stride);
+            const float* cf = c->conf + (size_t)i * c->conf_pitch;
+            float* u0 = c->f0 + (size_t)i * c->cols;
+            float* u1 = c->f1 + (size_t)i * c->cols;
+            for (int j = 0; j < c->cols; j++) { u0[j] = cf[j] * (float)d[j]; u1[j] = cf[j]; }
+            break;
+        }
+        case ROWS_EPILOGUE: {                     /* DF.cpp:295-296 */
+            int16_t* o = (int16_t*)((char*)c->i16 + (ptrdiff_t)i * c->i16_stride);
+            const float* u0 = c->f0 + (size_t)i * c->cols;
+            const float* u1 = c->f1 + (size_t)i * c->cols;
+            for (int j = 0; j < c->cols; j++) {
+                float rcp = 1.0f / (u1[j] + ADF_EPS);
+                o[j] = adf_oracle_sat16(u0[j] * rcp);
+            }
+            break;
+        }
+        }
+    }
 }
 
 /* ------------------------------------------------------------------ */
@@ -432,7 +633,8 @@ void adf_oracle_discontinuity(const int16_t* disp, ptrdiff_t stride, int W, int 
                               int rx, int ry, int rw, int rh, int radius, float roll_off,
                               float* dst, int threads)
 {
-    memset(dst, 0, sizeof(float) * (size_t)W * H);   /* Mat::zeros, DF.cpp:187-188 */
+    rows_ctx z = { ROWS_ZERO_F32, H, W, dst, NULL, 0, NULL, 0, NULL, NULL, 0, 0, 0, 0 };
+    parallel_stripes(threads, rows_stripe, &z);       /* Mat::zeros, DF.cpp:187-188 */
     if (rw <= 0 || rh <= 0) return;
     disc_ctx c = { disp, stride, W, rx, ry, rw, rh, radius, roll_off, dst };
     parallel_stripes(threads, disc_stripe, &c);
@@ -502,9 +704,9 @@ int adf_oracle_wls_filter(const adf_oracle_params* p, const int16_t* dispL, ptrd
     if (p->use_confidence && !dispR) return 1;                             /* DF.cpp:262 */
     const size_t P = (size_t)rw * rh;
     const int16_t fill = (int16_t)(16 * (0 - 1));  /* min_disp forced to 0: DF.cpp:149,254,284 */
-    for (int i = 0; i < H; i++) {
-        int16_t* o = (int16_t*)((char*)out + (ptrdiff_t)i * strideO);
-        for (int j = 0; j < W; j++) o[j] = fill;
+    {
+        rows_ctx fc = { ROWS_FILL_I16, H, W, NULL, NULL, fill, out, strideO, NULL, NULL, 0, 0, 0, 0 };
+        parallel_stripes(p->threads, rows_stripe, &fc);
     }
     const uint8_t* groi = guide + (ptrdiff_t)ry * strideG + (ptrdiff_t)rx * gch;
     int rc;
@@ -532,25 +734,19 @@ int adf_oracle_wls_filter(const adf_oracle_params* p, const int16_t* dispL, ptrd
     if (!conf || !planes) { if (!conf_out) free(conf); free(planes); return 4; }
     adf_oracle_confidence(dispL, strideL, dispR, strideR, W, H, rx, ry, rw, rh, p->disc_radius,
                           p->lrc_thresh, 1.0f, conf, p->threads);          /* DF.cpp:265 */
-    for (int i = 0; i < rh; i++) {                                         /* DF.cpp:286-290 */
-        const int16_t* d = (const int16_t*)((const char*)dispL + (ptrdiff_t)(ry + i) * strideL) + rx;
-        const float* c = conf + (size_t)(ry + i) * W + rx;
-        float* u0 = planes + (size_t)i * rw;
-        float* u1 = planes + P + (size_t)i * rw;
-        for (int j = 0; j < rw; j++) { u0[j] = c[j] * (float)d[j]; u1[j] = c[j]; }
+    {                                                                      /* DF.cpp:286-290 */
+        rows_ctx pc = { ROWS_PROLOGUE, rh, rw, planes, planes + P, 0, NULL, 0,
+                        (const int16_t*)((const char*)dispL + (ptrdiff_t)ry * strideL) + rx,
+                        conf + (size_t)ry * W + rx, strideL, W, 0, 0 };
+        parallel_stripes(p->threads, rows_stripe, &pc);
     }
     rc = adf_oracle_fgs_planes(groi, strideG, gch, rw, rh, planes, 2, p->lambda, p->sigma_color,
                                p->lambda_attenuation, p->num_iter, p->order, p->threads); /* :292-294 */
-    if (rc == 0)
-        for (int i = 0; i < rh; i++) {                                     /* DF.cpp:295-296 */
-            int16_t* o = (int16_t*)((char*)out + (ptrdiff_t)(ry + i) * strideO) + rx;
-            const float* u0 = planes + (size_t)i * rw;
-            const float* u1 = planes + P + (size_t)i * rw;
-            for (int j = 0; j < rw; j++) {
-                float rcp = 1.0f / (u1[j] + ADF_EPS);
-                o[j] = adf_oracle_sat16(u0[j] * rcp);
-            }
-        }
+    if (rc == 0) {                                                         /* DF.cpp:295-296 */
+        rows_ctx ec = { ROWS_EPILOGUE, rh, rw, planes, planes + P, 0,
+                        (int16_t*)((char*)out + (ptrdiff_t)ry * strideO) + rx, strideO, NULL, NULL, 0, 0, 0, 0 };
+        parallel_stripes(p->threads, rows_stripe, &ec);
+    }
     if (!conf_out) free(conf);
     free(planes);
     return rc;

@@ -137,6 +137,8 @@ int adf_oracle_wls_filter_scaled(const adf_oracle_params* p, const int16_t* disp
 /* saturate_cast<short>(float) = cvRound + clamp (DF.cpp:296, FGS.cpp:216);
  * exported so tests can probe the rounding convention directly. */
 int16_t adf_oracle_sat16(float v);
+/* test hook: ADF_ORDER_REF_SIMD one row / one column at a time (scalar emulation) instead of on 128-bit vectors */
+void adf_oracle_set_refsimd_rowwise(int on);
 
 /* ---- block matcher feeding the filter (adf_oracle_bm.c) ----
  * cv::StereoBM is external to the reference (calib3d, unpinned): parity unpinned; see adf_oracle_bm.c. */

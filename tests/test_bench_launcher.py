@@ -1,0 +1,61 @@
+"""`python bench.py --gpus N` without torchrun starts its own N workers.
+
+Dry mode: the launcher, the rendezvous (gloo, 127.0.0.1), the barriers and scalar all-reduces and the single JSON
+line run for real; the filter call is skipped, so no GPU is needed and `value` is 0 / `dry_run` true."""
+import json
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BENCH = os.path.join(ROOT, "bench.py")
+
+
+def _clean_env():
+    env = dict(os.environ)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "ADF_BENCH_WORKER"):
+        env.pop(k, None)
+    return env
+
+
+def test_self_launch_two_ranks_one_line():
+    p = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--dry-run", "--steps", "3", "--warmup", "1", "--pairs", "2"],
+                       cwd=ROOT, env=_clean_env(), capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, p.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["world_size"] == 2 and d["launcher"] == "self" and d["dry_run"] is True
+    assert d["steps"] == 3 and d["warmup"] == 1 and d["scaling"] == "weak"
+    assert len(d["per_rank_ms_per_step"]) == 2 and all(v > 0 for v in d["per_rank_ms_per_step"])
+    assert d["ms_per_step"] >= max(d["per_rank_ms_per_step"]) - 1e-6      # max over ranks, barrier to barrier
+    assert d["config"]["total_pairs"] == 4 and d["config"]["parallelism"] == "batch-sharded x2"
+    # checksum all-reduce: rank r contributes pairs * 16 * (r + 1)
+    assert d["checksum"] == 2 * 16 * (1 + 2)
+
+
+def test_already_under_a_launcher_is_a_worker():
+    """With RANK / WORLD_SIZE in the environment (torch.distributed.run) bench.py must not spawn again."""
+    env = _clean_env()
+    port = __import__("socket").socket()
+    port.bind(("127.0.0.1", 0))
+    env.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port.getsockname()[1]), WORLD_SIZE="2")
+    port.close()
+    procs = []
+    for r in range(2):
+        e = dict(env, RANK=str(r), LOCAL_RANK=str(r))
+        procs.append(subprocess.Popen([sys.executable, BENCH, "--gpus", "2", "--dry-run", "--steps", "2", "--warmup", "0"],
+                                      cwd=ROOT, env=e, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    outs = [p.communicate(timeout=300) for p in procs]
+    assert all(p.returncode == 0 for p in procs), [o[1][-2000:] for o in outs]
+    assert outs[1][0].strip() == ""
+    d = json.loads(outs[0][0].strip())
+    assert d["n_gpus"] == 2 and d["launcher"] == "torchrun"
+
+
+def test_worker_failure_propagates():
+    """A worker that dies takes the launcher's exit code with it (the driver must see rc != 0)."""
+    p = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--dry-run", "--config", "99"],
+                       cwd=ROOT, env=_clean_env(), capture_output=True, text=True, timeout=300)
+    assert p.returncode != 0
+    assert "bench launcher: rank" in p.stderr

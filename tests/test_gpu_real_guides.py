@@ -1,0 +1,82 @@
+"""Real-image guides.  Every other parity input is a synthetic scene (flat regions + sigma-6
+noise), which with sigma_color = 1.5 makes the smoothing systems nearly diagonal.  The reference's stereo module
+holds a KITTI-shaped pair (modules/stereo/testdata/imgKittyl.bmp / imgKitty.bmp, 1242x375 = BASELINE config 5's
+geometry; data fixtures under tests/golden/): real gradients exercise the mid range of the weight table and the
+strongly coupled regime.  Pipeline as in samples/disparity_filtering.cpp:151-189, every stage on the device,
+against the same pipeline of the oracle."""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+GOLDEN = os.path.join(os.path.dirname(__file__), "golden")
+MAX_DIF, MAX_MEAN_DIF = 1, 1 / 256.0          # test_disparity_wls_filter.cpp:104-105
+
+
+def load_kitti():
+    from PIL import Image
+    return [np.array(Image.open(os.path.join(GOLDEN, n)).convert("L")) for n in ("kitti_left.bmp", "kitti_right.bmp")]
+
+
+def _pipeline(adf, oracle, left, right, nd, wsz, roi, radius, sigma, guide=None):
+    import torch
+    guide = left if guide is None else guide
+    lm = adf.StereoBM.create(nd, wsz)
+    wls = adf.createDisparityWLSFilter(lm)                   # DF.cpp:386-414 (switches the matcher's own tests off)
+    rm = adf.createRightMatcher(lm)
+    tl, tr = torch.from_numpy(left).cuda(), torch.from_numpy(right).cuda()
+    dl, dr = lm.computeBoth(tl, tr)
+    assert torch.equal(dr, rm.compute(tr, tl))
+    edl = oracle.bm_compute(left, right, nd, wsz, 0)
+    edr = oracle.bm_compute(right, left, nd, wsz, -nd + 1)
+    assert np.array_equal(dl.cpu().numpy(), edl) and np.array_equal(dr.cpu().numpy(), edr)   # integer work: exact
+    p = oracle.default_params(threads=8, use_confidence=1, disc_radius=radius, sigma_color=sigma)
+    p.lambda_ = 8000.0
+    exp, exp_conf = oracle.wls_filter(edl, guide, edr, roi, p)
+    tg = torch.from_numpy(guide).cuda()
+    wls.setLambda(8000.0); wls.setSigmaColor(sigma); wls.setDepthDiscontinuityRadius(radius)
+    res = {}
+    for solver in (adf.SOLVER_EXACT, adf.SOLVER_WAVE):
+        wls.setSolver(solver)
+        out = wls.filter(dl, tg, None, dr, roi)
+        torch.cuda.synchronize()
+        assert wls.getLastSolver() == solver
+        assert np.array_equal(wls.getConfidenceMap().cpu().numpy(), exp_conf)              # confidence: bit-exact
+        res[solver] = np.abs(out.cpu().numpy().astype(np.int64) - exp.astype(np.int64))
+    assert res[adf.SOLVER_EXACT].max() == 0                                                 # scalar order: bit-exact
+    d = res[adf.SOLVER_WAVE]
+    assert d.max() <= MAX_DIF and d.mean() <= MAX_MEAN_DIF, (d.max(), d.mean())
+    return exp, exp_conf, edl
+
+
+def test_config5_kitti_pair(adf, oracle):
+    """BASELINE config 5 on the real pair: 1242x375, numDisparities 128 => ROI (128,0,1114,375), radius 2,
+    lambda 8000, sigma 1.5, 3 iterations, LRC confidence on."""
+    left, right = load_kitti()
+    assert left.shape == (375, 1242)
+    exp, conf, raw = _pipeline(adf, oracle, left, right, 128, 9, (128, 0, 1114, 375), 2, 1.5)
+    # the inputs really are in the coupled regime: a good share of the edge weights is far from 0 and from 1
+    ch, cv = oracle.weights(left[:, 128:], 1.5)
+    mid = ((-ch > 0.05) & (-ch < 0.95)).mean()
+    assert mid > 0.2, mid
+    assert (conf > 0).mean() > 0.2 and (exp[:, 128:] != raw[:, 128:]).mean() > 0.5
+
+
+def test_config5_kitti_pair_smooth_sigma(adf, oracle):
+    """Same pair with a sigma that keeps most neighbours coupled (c ~ -lambda): the hard end for the wave solver."""
+    left, right = load_kitti()
+    _pipeline(adf, oracle, left, right, 128, 9, (128, 0, 1114, 375), 2, 12.0)
+
+
+def test_config2_shape_real_guide(adf, oracle):
+    """BASELINE config 2's geometry (1920x1080, numDisparities 160 => ROI (160,0,1760,1080)) with a real guide: the
+    KITTI pair tiled (left and right the same way, so disparities stay consistent inside each tile), 3-channel
+    guide = the left view with two shifted copies as the other channels."""
+    left, right = load_kitti()
+    ty, tx = -(-1080 // left.shape[0]), -(-1920 // left.shape[1])
+    L = np.ascontiguousarray(np.tile(left, (ty, tx))[:1080, :1920])
+    R = np.ascontiguousarray(np.tile(right, (ty, tx))[:1080, :1920])
+    guide = np.ascontiguousarray(np.stack([L, np.roll(L, 1, 0), np.roll(L, 1, 1)], axis=2))
+    _pipeline(adf, oracle, L, R, 160, 15, (160, 0, 1760, 1080), 2, 1.5, guide=guide)

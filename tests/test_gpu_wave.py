@@ -264,3 +264,31 @@ def test_device_call_is_graph_capturable(adf):
         g.replay()
     torch.cuda.synchronize()
     assert torch.equal(out, ref) and torch.equal(f.getConfidenceMap(), ref_conf)
+
+
+def test_batch_beyond_4gb_workspace(adf, oracle):
+    """a batch whose workspace and planes exceed 4 GB (20 pairs of 3840x2160: 4.5 GB of planes,
+    every per-pair offset needs 64 bits) -- pairs 0, middle and last equal the single-pair call, and the last pair
+    (the one the largest offsets reach) is checked against the oracle."""
+    import torch
+    n, cfg = 20, synthetic.CONFIGS[3]
+    W, H, roi, radius = cfg["W"], cfg["H"], cfg["roi"], cfg["radius"]
+    dev = torch.device("cuda:0")
+    view, dl, dr = synthetic.make_artificial_batch_torch(n, W, H, 3, 4242, cfg["rect_disparity"], dev)
+    f = adf.createDisparityWLSFilterGeneric(True)
+    f.setSolver(adf.SOLVER_WAVE); f.setLambda(8000.0); f.setSigmaColor(1.5); f.setDepthDiscontinuityRadius(radius)
+    out = f.filter(dl, view, None, dr, roi)
+    torch.cuda.synchronize()
+    assert f.getLastSolver() == adf.SOLVER_WAVE and f.workspaceBytes() > (4 << 30)
+    one = adf.createDisparityWLSFilterGeneric(True)
+    one.setSolver(adf.SOLVER_WAVE); one.setLambda(8000.0); one.setSigmaColor(1.5); one.setDepthDiscontinuityRadius(radius)
+    for k in (0, n // 2, n - 1):
+        single = one.filter(dl[k], view[k], None, dr[k], roi)
+        assert torch.equal(single, out[k]), k
+        assert torch.equal(one.getConfidenceMap(), f.getConfidenceMap(k)), k
+    p = oracle.default_params(sigma_color=1.5, disc_radius=radius, threads=16)
+    p.lambda_ = 8000.0
+    exp, exp_conf = oracle.wls_filter(dl[n - 1].cpu().numpy(), view[n - 1].cpu().numpy(), dr[n - 1].cpu().numpy(), roi, p)
+    assert np.array_equal(f.getConfidenceMap(n - 1).cpu().numpy(), exp_conf)
+    d = np.abs(out[n - 1].cpu().numpy().astype(np.int64) - exp)
+    assert d.max() <= MAX_DIF and d.mean() <= MAX_MEAN_DIF, (d.max(), d.mean())

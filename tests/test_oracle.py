@@ -205,3 +205,19 @@ def test_generic_fgs_depths(oracle):
         if cn > 1:
             one = oracle.fgs_filter(guide, np.ascontiguousarray(src[..., 1]), 900.0, 20.0)
             assert np.array_equal(res[..., 1], one)
+
+
+def test_refsimd_vector_code_equals_its_scalar_emulation(oracle):
+    """ADF_ORDER_REF_SIMD runs four rows / four columns at a time on 128-bit vectors (what the reference's default
+    build does, FGS.cpp:295-351, 516-548); every lane must perform the operations of the scalar emulation of that
+    order, bit for bit, at widths / heights that leave every kind of tail."""
+    rng = np.random.default_rng(11)
+    for (h, w) in ((37, 53), (8, 4), (5, 3), (64, 129), (11, 2), (4, 1)):
+        guide = rng.integers(0, 255, (h, w, 3), dtype=np.uint8)
+        src = rng.normal(0, 500, (h, w)).astype(np.float32)
+        for threads in (1, 3):
+            oracle.set_refsimd_rowwise(True)
+            a = oracle.fgs_filter(guide, src, 8000.0, 7.0, order=oracle.ORDER_REF_SIMD, threads=threads)
+            oracle.set_refsimd_rowwise(False)
+            b = oracle.fgs_filter(guide, src, 8000.0, 7.0, order=oracle.ORDER_REF_SIMD, threads=threads)
+            assert np.array_equal(a, b), (h, w, threads)

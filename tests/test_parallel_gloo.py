@@ -74,3 +74,69 @@ def test_scatter_gather_world2(n_total):
     for rank, ok_s, ok_g, tmax, tsum in results:
         assert ok_s and ok_g
         assert tmax == 2.0 and tsum == 3.0
+
+
+def _pipe_worker(rank, world, port, n_total, n_sub, q):
+    import torch.distributed as dist
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        dev = torch.device("cpu")
+        shapes = [(3, 5, 2), (3, 5), (3, 5)]
+        dtypes = [torch.uint8, torch.int16, torch.int16]
+        full = None
+        if rank == 0:
+            g = torch.Generator().manual_seed(5)
+            full = [torch.randint(0, 200, (n_total,) + s, generator=g).to(d) for s, d in zip(shapes, dtypes)]
+        calls = []
+
+        def process(v, a, b, o):            # stands in for DisparityWLSFilter.filter on one sub-batch
+            calls.append(int(a.shape[0]))
+            o.copy_((a.to(torch.int32) * 2 - b.to(torch.int32) + v[..., 0].to(torch.int32)).to(torch.int16))
+
+        stats, out = parallel.pipelined_scatter_filter_gather(full, n_total, shapes, dtypes, (3, 5), torch.int16, dev,
+                                                              process, n_sub)
+        ok = True
+        if rank == 0:
+            exp = (full[1].to(torch.int32) * 2 - full[2].to(torch.int32) + full[0][..., 0].to(torch.int32)).to(torch.int16)
+            ok = bool(torch.equal(out, exp))
+        else:
+            ok = out is None
+        a, b = parallel.shard_range(n_total, rank, world)
+        q.put((rank, ok, sum(calls) == b - a, stats["sub_batches"], stats["total_ms"] > 0))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n_total,n_sub", [(16, 4), (9, 4), (2, 4), (7, 1)])
+def test_pipelined_scatter_filter_gather_world2(n_total, n_sub):
+    """sub-batch s+1 travels while sub-batch s is filtered; every pair is filtered exactly once and
+    lands in the root's output at its own index, whatever the shard / sub-batch raggedness."""
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_pipe_worker, args=(r, world, port, n_total, n_sub, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    subs = {r[3] for r in results}
+    assert len(subs) == 1 and subs.pop() == max(1, min(n_sub, max(1, n_total // world)))
+    for rank, ok, counted, _, timed in results:
+        assert ok and counted and timed
+
+
+def test_sub_ranges_tile_every_shard():
+    for n in (1, 7, 64, 513):
+        for world in (1, 2, 8):
+            for n_sub in (1, 3, 4):
+                for r in range(world):
+                    a, b = parallel.shard_range(n, r, world)
+                    spans = [parallel.sub_range(n, r, world, s, n_sub) for s in range(n_sub)]
+                    assert spans[0][0] == a and spans[-1][1] == b
+                    assert all(spans[i][1] == spans[i + 1][0] for i in range(n_sub - 1))
