@@ -62,13 +62,16 @@ SYMBOLS = [
     ("adf_wls_filter_scaled_host", _i, _FILTER_SCALED_DEV[:-1]),
     ("adf_wls_get_confidence_device", _i, [_vp, _i, _vp, _pd, _vp]),
     ("adf_wls_get_confidence_host", _i, [_vp, _i, _vp, _pd]),
+    ("adf_wls_get_device", _i, [_vp, C.POINTER(_i)]),
     ("adf_wls_get_roi", _i, [_vp, C.POINTER(Rect)]),
     ("adf_wls_sync", _i, [_vp, _vp]),
     ("adf_wls_workspace_bytes", _sz, [_vp]),
     ("adf_wls_profile_enable", _i, [_vp, _i]),
     ("adf_wls_profile_read", _i, [_vp, _vp, _i, C.POINTER(_i)]),
     ("adf_fgs_create", _i, [C.POINTER(_vp), _vp, _pd, _i, _i, _i, _d, _d, _d, _i, _i]),
+    ("adf_fgs_create_device", _i, [C.POINTER(_vp), _vp, _pd, _i, _i, _i, _d, _d, _d, _i, _i, _vp]),
     ("adf_fgs_destroy", None, [_vp]),
+    ("adf_fgs_get_device", _i, [_vp, C.POINTER(_i)]),
     ("adf_fgs_filter_host", _i, [_vp, _vp, _pd, _vp, _pd, _i, _i]),
     ("adf_fgs_filter_device", _i, [_vp, _vp, _pd, _vp, _pd, _i, _i, _vp]),
     ("adf_compute_mse_host", _i, [_vp, _pd, _vp, _pd, _i, _i, C.POINTER(Rect), C.POINTER(_d)]),
@@ -80,6 +83,7 @@ SYMBOLS = [
     ("adf_bm_create", _i, [C.POINTER(_vp), _i, _i]),
     ("adf_bm_destroy", None, [_vp]),
     ("adf_bm_set_params", _i, [_vp, _i, _i, _i, _i, _i, _i]),
+    ("adf_bm_get_device", _i, [_vp, C.POINTER(_i)]),
     ("adf_bm_get_params", _i, [_vp] + [C.POINTER(_i)] * 6),
     ("adf_bm_compute_device", _i, [_vp, _i, _vp, _pd, _pd, _vp, _pd, _pd, _i, _i, _vp, _pd, _pd, _vp]),
     ("adf_bm_compute_both_device", _i, [_vp, _i, _vp, _pd, _pd, _vp, _pd, _pd, _i, _i, _vp, _pd, _pd, _vp, _pd, _pd, _vp]),

@@ -361,6 +361,7 @@ extern "C" int adf_wls_set_solver(adf_wls_t* h, int solver)
 extern "C" int adf_wls_get_solver(const adf_wls_t* h, int* v) { NEED_HANDLE(h); if (v) *v = h->solver; return ADF_OK; }
 extern "C" int adf_wls_get_last_solver(const adf_wls_t* h, int* v) { NEED_HANDLE(h); if (v) *v = h->last_solver; return ADF_OK; }
 
+extern "C" int adf_wls_get_device(const adf_wls_t* h, int* device) { NEED_HANDLE(h); if (device) *device = h->device; return ADF_OK; }
 extern "C" int adf_wls_get_roi(const adf_wls_t* h, adf_rect* roi) { NEED_HANDLE(h); if (roi) *roi = h->roi; return ADF_OK; }
 extern "C" size_t adf_wls_workspace_bytes(const adf_wls_t* h)
 {
@@ -787,8 +788,10 @@ struct adf_fgs {
     DevBuf io;     // src / dst image staging
 };
 
-extern "C" int adf_fgs_create(adf_fgs_t** out, const uint8_t* guide, ptrdiff_t gstride, int gch, int w, int hgt,
-                              double lambda, double sigma_color, double atten, int num_iter, int solver)
+// guide_on_device: `guide` is a HIP device pointer (copied into the handle on `st`, no host round trip).
+static int fgs_create_impl(adf_fgs_t** out, const uint8_t* guide, ptrdiff_t gstride, int gch, int w, int hgt,
+                           double lambda, double sigma_color, double atten, int num_iter, int solver,
+                           bool guide_on_device, hipStream_t st)
 {
     if (!out) return fail(ADF_EBADARG, "adf_fgs_create: out is NULL");
     *out = nullptr;
@@ -808,13 +811,14 @@ extern "C" int adf_fgs_create(adf_fgs_t** out, const uint8_t* guide, ptrdiff_t g
     f->num_iter = num_iter;
     f->g = make_geom(w, hgt, 0, 0, w, hgt);
     f->solver = (solver == ADF_SOLVER_WAVE && wave_fits(f->g)) ? ADF_SOLVER_WAVE : ADF_SOLVER_EXACT;
-    hipStream_t st = nullptr;
     int rc = f->lut.ensure(f->sigma, st);
     if (!rc) rc = f->planes.reserve(6 * f->g.plane * sizeof(float), st);
     const size_t gbytes = (size_t)w * hgt * gch;
     if (!rc) rc = f->io.reserve(gbytes > (size_t)w * hgt * 16 ? gbytes : (size_t)w * hgt * 16, st);
     if (rc) { adf_fgs_destroy(f); return rc; }
-    hipError_t e = hipMemcpy2D(f->io.p, (size_t)w * gch, guide, gstride, (size_t)w * gch, hgt, hipMemcpyHostToDevice);
+    hipError_t e = guide_on_device
+        ? hipMemcpy2DAsync(f->io.p, (size_t)w * gch, guide, gstride, (size_t)w * gch, hgt, hipMemcpyDeviceToDevice, st)
+        : hipMemcpy2D(f->io.p, (size_t)w * gch, guide, gstride, (size_t)w * gch, hgt, hipMemcpyHostToDevice);
     if (e == hipSuccess) {
         float* base = (float*)f->planes.p;
         WeightArgs wa{(const uint8_t*)f->io.p, (ptrdiff_t)w * gch, 0, gch, (const float*)f->lut.dev.p,
@@ -823,11 +827,28 @@ extern "C" int adf_fgs_create(adf_fgs_t** out, const uint8_t* guide, ptrdiff_t g
                       f->solver == ADF_SOLVER_WAVE ? nullptr : base + 5 * f->g.plane};   // B0
         e = launch_weights(wa, 1, st);
     }
-    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    // host guide: the weights are finished when create returns, like the reference's init (FGS.cpp:163-172);
+    // device guide: they are queued on `st`, the stream the filter calls are expected on
+    if (e == hipSuccess && !guide_on_device) e = hipStreamSynchronize(st);
     if (e != hipSuccess) { adf_fgs_destroy(f); return fail(ADF_EHIP, "adf_fgs_create: %s", hipGetErrorString(e)); }
     *out = f;
     return ADF_OK;
 }
+
+extern "C" int adf_fgs_create(adf_fgs_t** out, const uint8_t* guide, ptrdiff_t gstride, int gch, int w, int hgt,
+                              double lambda, double sigma_color, double atten, int num_iter, int solver)
+{
+    return fgs_create_impl(out, guide, gstride, gch, w, hgt, lambda, sigma_color, atten, num_iter, solver, false, nullptr);
+}
+
+extern "C" int adf_fgs_create_device(adf_fgs_t** out, const uint8_t* guide, ptrdiff_t gstride, int gch, int w, int hgt,
+                                     double lambda, double sigma_color, double atten, int num_iter, int solver, void* stream)
+{
+    return fgs_create_impl(out, guide, gstride, gch, w, hgt, lambda, sigma_color, atten, num_iter, solver, true,
+                           (hipStream_t)stream);
+}
+
+extern "C" int adf_fgs_get_device(const adf_fgs_t* f, int* device) { NEED_HANDLE(f); if (device) *device = f->device; return ADF_OK; }
 
 extern "C" void adf_fgs_destroy(adf_fgs_t* f)
 {

@@ -446,6 +446,13 @@ extern "C" int adf_bm_set_params(adf_bm_t* h, int min_disparity, int num_dispari
     return ADF_OK;
 }
 
+extern "C" int adf_bm_get_device(const adf_bm_t* h, int* device)
+{
+    if (!h) return bm_fail(ADF_EBADARG, "handle is NULL");
+    if (device) *device = h->device;
+    return ADF_OK;
+}
+
 extern "C" int adf_bm_get_params(const adf_bm_t* h, int* min_disparity, int* num_disparities, int* block_size,
                                  int* prefilter_cap, int* texture_threshold, int* uniqueness_ratio)
 {

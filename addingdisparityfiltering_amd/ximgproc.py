@@ -105,6 +105,17 @@ def _stream_of(img):
     return None
 
 
+def _check_device(getter, handle, imgs, what):
+    """A handle's workspace lives on the device that was current when it was created (include/adf_wls.h):
+    tensors of another GPU would pair it with foreign pointers and a foreign stream."""
+    dev = C.c_int(-1)
+    _lib.check(getter(handle, C.byref(dev)))
+    for im in imgs:
+        if im is not None and im.device and im.keep.device.index != dev.value:
+            raise AdfError(_lib.ADF_EBADARG, "%s lives on cuda:%d; tensors on cuda:%s cannot be passed to it "
+                                             "(create one handle per GPU)" % (what, dev.value, im.keep.device.index))
+
+
 class DisparityFilter:
     """Main interface for all disparity map filters (DF.hpp:52-76)."""
 
@@ -224,6 +235,7 @@ class DisparityWLSFilter(DisparityFilter):
         out = _Image(filtered_disparity_map, np.int16, "filtered_disparity_map", batched)
         if (out.n, out.h, out.w) != (gv.n, gv.h, gv.w) or out.device != dl.device:               # DF.cpp:252,282
             raise AdfError(_lib.ADF_ESIZE, "filtered_disparity_map has the wrong size or placement")
+        _check_device(_lib.lib().adf_wls_get_device, self._h, imgs + [out], "this DisparityWLSFilter")
         roi = _as_rect(ROI)
         args = [self._h, dl.n,
                 C.c_void_p(dl.ptr), dl.stride, dl.pair_stride, dl.w, dl.h,
@@ -341,6 +353,7 @@ class StereoBM(StereoMatcher):
             h = C.c_void_p()
             _lib.check(lib.adf_bm_create(C.byref(h), int(self.numDisparities), int(self.blockSize)))
             self._h = h
+        _check_device(lib.adf_bm_get_device, self._h, [L, R, D], "this StereoBM")
         _lib.check(lib.adf_bm_set_params(self._h, int(self.minDisparity), int(self.numDisparities), int(self.blockSize),
                                          int(self.preFilterCap), int(self.textureThreshold), int(self.uniquenessRatio)))
         args = [self._h, L.n, C.c_void_p(L.ptr), L.stride, L.pair_stride, C.c_void_p(R.ptr), R.stride, R.pair_stride,
@@ -354,7 +367,11 @@ class StereoBM(StereoMatcher):
     def computeBoth(self, left, right, disparity_left=None, disparity_right=None):
         """Extension: this matcher's map AND the map of createRightMatcher(self) (DF.cpp:417-431) from one launch --
         identical to `self.compute(left, right)` and `createRightMatcher(self).compute(right, left)`, with the views
-        prefiltered once and both searches in one grid (worth it for one pair per call).  Device tensors only."""
+        prefiltered once and both searches in one grid (worth it for one pair per call).  Device tensors only.
+
+        The reference's right matcher keeps cv::StereoBM's default preFilterCap of 31 (DF.cpp:421-431 copy every
+        parameter BUT the cap), so one shared prefilter is only the same computation when this matcher's cap is 31
+        too; with any other cap the two maps are produced by the two separate computes (same results, two launches)."""
         batched = len(left.shape) == 3
         L = _Image(left, np.uint8, "left", batched)
         R = _Image(right, np.uint8, "right", batched)
@@ -373,11 +390,22 @@ class StereoBM(StereoMatcher):
         for D in (DL, DR):
             if (D.n, D.h, D.w) != (L.n, L.h, L.w) or not D.device:
                 raise AdfError(_lib.ADF_ESIZE, "disparity maps must match the views")
+        if self.preFilterCap != 31:
+            if getattr(self, "_right", None) is None:
+                self._right = StereoBM(1, 5)
+            rm = createRightMatcher(self)
+            for k in ("minDisparity", "numDisparities", "blockSize", "textureThreshold", "uniquenessRatio",
+                      "preFilterCap", "disp12MaxDiff", "speckleWindowSize"):
+                setattr(self._right, k, getattr(rm, k))
+            self.compute(left, right, disparity_left)
+            self._right.compute(right, left, disparity_right)
+            return disparity_left, disparity_right
         lib = _lib.lib()
         if self._h is None:
             h = C.c_void_p()
             _lib.check(lib.adf_bm_create(C.byref(h), int(self.numDisparities), int(self.blockSize)))
             self._h = h
+        _check_device(lib.adf_bm_get_device, self._h, [L, R, DL, DR], "this StereoBM")
         _lib.check(lib.adf_bm_set_params(self._h, int(self.minDisparity), int(self.numDisparities), int(self.blockSize),
                                          int(self.preFilterCap), int(self.textureThreshold), int(self.uniquenessRatio)))
         _lib.check(lib.adf_bm_compute_both_device(
@@ -468,6 +496,24 @@ def createDisparityWLSFilterGeneric(use_confidence):
 # ---------------------------------------------------------------------------------------------
 class FastGlobalSmootherFilter:
     def __init__(self, guide, lambda_, sigma_color, lambda_attenuation=0.25, num_iter=3, solver=SOLVER_WAVE):
+        self._h = C.c_void_p()
+        if _is_torch(guide) and guide.is_cuda:
+            # the guide already lives in HBM (a device pipeline, e.g. sparse_match_interpolators.cpp:202-203):
+            # adf_fgs_create_device, asynchronous on torch's current stream, nothing crosses PCIe
+            if guide.numel() == 0:
+                raise AdfError(_lib.ADF_EBADARG, "guide is empty")  # FGS.cpp:143
+            if guide.dtype != torch.uint8 or guide.dim() not in (2, 3) or (guide.dim() == 3 and guide.shape[2] not in (1, 3)):
+                raise AdfError(_lib.ADF_EBADARG, "guide must be CV_8UC1 or CV_8UC3")  # FGS.cpp:144
+            gt = guide.contiguous()
+            ch = 1 if gt.dim() == 2 else gt.shape[2]
+            self._shape = tuple(gt.shape[:2])
+            with torch.cuda.device(gt.device):
+                st = C.c_void_p(torch.cuda.current_stream(gt.device).cuda_stream)
+                _lib.check(_lib.lib().adf_fgs_create_device(C.byref(self._h), C.c_void_p(gt.data_ptr()), gt.shape[1] * ch,
+                                                            ch, gt.shape[1], gt.shape[0], float(lambda_), float(sigma_color),
+                                                            float(lambda_attenuation), int(num_iter), int(solver), st))
+            self._guide_keep = gt      # the copy into the handle is queued on the stream: keep the source alive
+            return
         if guide is None or getattr(guide, "size", 0) == 0:
             raise AdfError(_lib.ADF_EBADARG, "guide is empty")  # FGS.cpp:143
         g = np.ascontiguousarray(guide)
@@ -475,7 +521,6 @@ class FastGlobalSmootherFilter:
             raise AdfError(_lib.ADF_EBADARG, "guide must be CV_8UC1 or CV_8UC3")  # FGS.cpp:144
         ch = 1 if g.ndim == 2 else g.shape[2]
         self._shape = g.shape[:2]
-        self._h = C.c_void_p()
         _lib.check(_lib.lib().adf_fgs_create(C.byref(self._h), C.c_void_p(g.ctypes.data), g.shape[1] * ch, ch,
                                              g.shape[1], g.shape[0], float(lambda_), float(sigma_color),
                                              float(lambda_attenuation), int(num_iter), int(solver)))
@@ -506,6 +551,9 @@ class FastGlobalSmootherFilter:
                            "Size of the filtered image must be equal to the size of the guide image")  # FGS.cpp:187
         if dst is None:
             dst = np.empty_like(s)
+        elif not (isinstance(dst, np.ndarray) and dst.flags["C_CONTIGUOUS"] and dst.shape == s.shape and dst.dtype == s.dtype):
+            # the library writes h rows of w*cn elements at a dense stride: anything else would be overrun
+            raise AdfError(_lib.ADF_ESIZE, "dst must be a C-contiguous ndarray with src's shape and dtype")
         rowb = s.shape[1] * cn * s.itemsize
         _lib.check(_lib.lib().adf_fgs_filter_host(self._h, C.c_void_p(s.ctypes.data), rowb,
                                                   C.c_void_p(dst.ctypes.data), rowb, depth, cn))
@@ -528,6 +576,10 @@ class FastGlobalSmootherFilter:
         elif not (_is_torch(dst) and dst.is_cuda and dst.is_contiguous() and dst.shape == s.shape and dst.dtype == s.dtype):
             raise AdfError(_lib.ADF_EBADARG, "dst must be a contiguous CUDA tensor shaped like src")
         rowb = s.shape[1] * cn * s.element_size()
+        dev = C.c_int(-1)
+        _lib.check(_lib.lib().adf_fgs_get_device(self._h, C.byref(dev)))
+        if s.device.index != dev.value or dst.device.index != dev.value:
+            raise AdfError(_lib.ADF_EBADARG, "this FastGlobalSmootherFilter lives on cuda:%d" % dev.value)
         st = C.c_void_p(torch.cuda.current_stream(s.device).cuda_stream)
         _lib.check(_lib.lib().adf_fgs_filter_device(self._h, C.c_void_p(s.data_ptr()), rowb,
                                                     C.c_void_p(dst.data_ptr()), rowb, depth, cn, st))

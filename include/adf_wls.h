@@ -17,6 +17,12 @@
  *   - a handle owns a device workspace that is sized on first use and reused; a
  *     handle serves one caller at a time (the reference objects are not
  *     re-entrant either: DF.cpp:224-233, FGS.cpp:202-223);
+ *   - a handle is bound to the HIP device that was current when it was created
+ *     (adf_*_get_device) and to ONE stream at a time: every call on a handle
+ *     stages through the same workspace, so two calls on different streams must
+ *     be ordered by the caller (an event, or adf_wls_sync) -- nothing inside the
+ *     library serialises them.  Device pointers must belong to the handle's
+ *     device.  Concurrency = several handles, each on its own stream;
  *   - every function returns ADF_OK or an error code; adf_last_error() gives the
  *     message of the calling thread's last failure (the reference throws
  *     cv::Exception from CV_Assert / CV_Error: DF.cpp:221-222,262-264,
@@ -153,6 +159,9 @@ int adf_wls_filter_scaled_host(adf_wls_t* h, int n_pairs,
  * next filter call on the handle. */
 int adf_wls_get_confidence_device(adf_wls_t* h, int pair, float* dst, ptrdiff_t dst_stride, void* stream);
 int adf_wls_get_confidence_host(adf_wls_t* h, int pair, float* dst, ptrdiff_t dst_stride);
+/* The HIP device the handle's workspace lives on (the device current at adf_wls_create); device
+ * pointers and streams passed to the handle must belong to it. */
+int adf_wls_get_device(const adf_wls_t* h, int* device);
 /* getROI() (DF.hpp:120, DF.cpp:139): ROI used by the last filter call. */
 int adf_wls_get_roi(const adf_wls_t* h, adf_rect* roi);
 /* Block until everything the handle queued on `stream` has finished. */
@@ -184,7 +193,16 @@ int adf_wls_profile_read(adf_wls_t* h, adf_kernel_time* out, int capacity, int* 
 int adf_fgs_create(adf_fgs_t** out, const uint8_t* guide, ptrdiff_t guide_stride, int guide_channels,
                    int w, int h, double lambda, double sigma_color, double lambda_attenuation,
                    int num_iter, int solver);
+/* The same with the guide already resident in HBM (a DEVICE pointer): nothing crosses PCIe and nothing
+ * synchronises -- the guide copy and the weight kernel are queued on `stream`, which is also the stream the
+ * handle's filter calls are expected on.  For device pipelines such as the second in-tree caller, which
+ * smooths flow fields against an image it already holds (sparse_match_interpolators.cpp:202-203:
+ * fastGlobalSmootherFilter(prevImage, flow, ...)). */
+int adf_fgs_create_device(adf_fgs_t** out, const uint8_t* guide, ptrdiff_t guide_stride, int guide_channels,
+                          int w, int h, double lambda, double sigma_color, double lambda_attenuation,
+                          int num_iter, int solver, void* stream);
 void adf_fgs_destroy(adf_fgs_t* h);
+int adf_fgs_get_device(const adf_fgs_t* h, int* device);
 
 /* FastGlobalSmootherFilter::filter(src, dst) (EF.hpp:370, FGS.cpp:182-233).
  * src/dst: HOST pointers, same size as the guide, depth ADF_8U / ADF_16S / ADF_32F,
@@ -239,6 +257,7 @@ void adf_bm_destroy(adf_bm_t* h);
  * minDisparity = -(min_disp+num_disp)+1, :424).  Values are checked at compute time like cv::StereoBM. */
 int adf_bm_set_params(adf_bm_t* h, int min_disparity, int num_disparities, int block_size,
                       int prefilter_cap, int texture_threshold, int uniqueness_ratio);
+int adf_bm_get_device(const adf_bm_t* h, int* device);
 int adf_bm_get_params(const adf_bm_t* h, int* min_disparity, int* num_disparities, int* block_size,
                       int* prefilter_cap, int* texture_threshold, int* uniqueness_ratio);
 /* StereoMatcher::compute(left, right, disparity) on a batch of n_pairs equally sized CV_8UC1 pairs laid out

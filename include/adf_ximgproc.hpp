@@ -308,7 +308,7 @@ inline Ptr<StereoBM> createRightMatcher(const Ptr<StereoBM>& matcher_left)
     right_bm->setUniquenessRatio(0);
     right_bm->setDisp12MaxDiff(1000000);
     right_bm->setSpeckleWindowSize(0);
-    right_bm->setPreFilterCap(matcher_left->getPreFilterCap());
+    // (the reference's BM branch does not copy preFilterCap: the right matcher keeps cv::StereoBM's default 31)
     return right_bm;
 }
 

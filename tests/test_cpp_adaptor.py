@@ -28,6 +28,19 @@ def _compile():
     return EXE
 
 
+def _typecheck_opencv_branch():
+    """The cv::Mat / cv::StereoMatcher branch of the adaptor, type-checked (-fsyntax-only, never linked) against
+    declaration stubs of the few cv:: names it touches (tests/cpp/opencv_stub/): the image has no OpenCV, and
+    without this the branch a cv::Mat pipeline takes would never meet a compiler."""
+    cpp = os.path.join(ROOT, "tests", "cpp")
+    subprocess.run(["g++", "-std=c++17", "-fsyntax-only", "-Wall", "-Wextra", "-I", os.path.join(cpp, "opencv_stub"),
+                    "-I", os.path.join(ROOT, "include"), os.path.join(cpp, "typecheck_opencv_branch.cpp")], check=True)
+
+
+def test_opencv_branch_typechecks():
+    _typecheck_opencv_branch()
+
+
 def test_adaptor_compiles_without_opencv():
     assert os.path.exists(_compile())
 

@@ -1,0 +1,87 @@
+"""Boundary loose ends: device-resident guide for the FGS sub-boundary, output
+validation of the host FGS path, the right matcher's prefilter cap, handle / tensor device agreement."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def test_fgs_device_guide_equals_host_guide(adf, oracle):
+    """adf_fgs_create_device: the guide never leaves HBM (sparse_match_interpolators.cpp:202-203 is the in-tree
+    caller shape: a 2-channel float flow field smoothed against an image the pipeline already holds)."""
+    import torch
+    from addingdisparityfiltering_amd.ximgproc import FastGlobalSmootherFilter, fastGlobalSmootherFilter
+
+    rng = np.random.default_rng(9)
+    h, w = 270, 481
+    for gshape in ((h, w, 3), (h, w)):
+        guide = rng.integers(0, 255, gshape, dtype=np.uint8)
+        flow = rng.normal(0, 30, (h, w, 2)).astype(np.float32)
+        tg, tf = torch.from_numpy(guide).cuda(), torch.from_numpy(flow).cuda()
+        for solver in (adf.SOLVER_EXACT, adf.SOLVER_WAVE):
+            host = FastGlobalSmootherFilter(guide, 500.0, 1.5, solver=solver).filter(flow)
+            f = FastGlobalSmootherFilter(tg, 500.0, 1.5, solver=solver)          # device guide
+            dev = f.filter(tf)
+            assert dev.is_cuda and np.array_equal(dev.cpu().numpy(), host)
+            one = fastGlobalSmootherFilter(tg, tf, 500.0, 1.5, solver=solver)    # EF.hpp:413, all on the device
+            assert np.array_equal(one.cpu().numpy(), host)
+        exp = oracle.fgs_filter(guide, flow, 500.0, 1.5, threads=8)
+        assert np.array_equal(FastGlobalSmootherFilter(tg, 500.0, 1.5, solver=adf.SOLVER_EXACT).filter(tf).cpu().numpy(), exp)
+    # a strided (non-contiguous) device guide is made dense before the call
+    big = torch.from_numpy(rng.integers(0, 255, (h, w + 7), dtype=np.uint8)).cuda()
+    g2 = big[:, 3:3 + w]
+    a = FastGlobalSmootherFilter(g2, 500.0, 1.5).filter(tf)
+    b = FastGlobalSmootherFilter(g2.cpu().numpy(), 500.0, 1.5).filter(tf)
+    assert torch.equal(a, b)
+    with pytest.raises(adf.AdfError):
+        FastGlobalSmootherFilter(torch.zeros((h, w, 2), dtype=torch.uint8, device="cuda"), 500.0, 1.5)
+    with pytest.raises(adf.AdfError):
+        FastGlobalSmootherFilter(torch.zeros((h, w), dtype=torch.float32, device="cuda"), 500.0, 1.5)
+
+
+def test_fgs_host_dst_is_validated(adf):
+    """a caller-supplied dst that is smaller, strided or of another dtype must be refused, not overrun."""
+    from addingdisparityfiltering_amd.ximgproc import FastGlobalSmootherFilter
+    rng = np.random.default_rng(2)
+    guide = rng.integers(0, 255, (40, 60), dtype=np.uint8)
+    src = rng.normal(0, 10, (40, 60)).astype(np.float32)
+    f = FastGlobalSmootherFilter(guide, 100.0, 2.0)
+    ok = np.empty_like(src)
+    assert f.filter(src, ok) is ok
+    for bad in (np.empty((39, 60), np.float32), np.empty((40, 60), np.int16), np.empty((40, 120), np.float32)[:, ::2],
+                np.empty((40, 60, 1), np.float32)):
+        with pytest.raises(adf.AdfError):
+            f.filter(src, bad)
+
+
+def test_right_matcher_keeps_default_prefilter_cap(adf, oracle):
+    """DF.cpp:421-431 copies every parameter of the left StereoBM into the right matcher EXCEPT preFilterCap (it stays
+    at cv::StereoBM's default 31).  computeBoth must equal createRightMatcher(self).compute(right, left) for any cap."""
+    import torch
+    from test_gpu_bm import _views
+    left, right = _views(77, 48, 260, shift=6)
+    tl, tr = torch.from_numpy(left).cuda(), torch.from_numpy(right).cuda()
+    for cap in (31, 12, 63):
+        lm = adf.StereoBM.create(32, 9)
+        lm.setPreFilterCap(cap); lm.setTextureThreshold(0); lm.setUniquenessRatio(0)
+        rm = adf.createRightMatcher(lm)
+        assert rm.getPreFilterCap() == 31
+        dl, dr = lm.computeBoth(tl, tr)
+        assert torch.equal(dl, lm.compute(tl, tr)) and torch.equal(dr, rm.compute(tr, tl))
+        assert np.array_equal(dl.cpu().numpy(), oracle.bm_compute(left, right, 32, 9, 0, cap))
+        assert np.array_equal(dr.cpu().numpy(), oracle.bm_compute(right, left, 32, 9, -31, 31))
+
+
+def test_handle_reports_its_device(adf):
+    import ctypes as C
+    import torch
+    from addingdisparityfiltering_amd import _lib
+    f = adf.createDisparityWLSFilterGeneric(True)
+    d = C.c_int(-1)
+    _lib.check(_lib.lib().adf_wls_get_device(f._h, C.byref(d)))
+    assert d.value == torch.cuda.current_device()
+    if torch.cuda.device_count() > 1:                     # one-GPU boxes cannot build a foreign tensor
+        other = torch.device("cuda", (d.value + 1) % torch.cuda.device_count())
+        z = torch.zeros((8, 8), dtype=torch.int16, device=other)
+        with pytest.raises(adf.AdfError):
+            f.filter(z, torch.zeros((8, 8), dtype=torch.uint8, device=other), None, z)
