@@ -287,6 +287,7 @@ struct adf_wls {
     hipStream_t side = nullptr;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     bool overlap = true;
+    bool conf_band = true;   // ADF_CONF_BAND=0: the two-kernel confidence stage (A/B measurements)
     int ensure_side()
     {
         if (side) return ADF_OK;
@@ -316,6 +317,7 @@ extern "C" int adf_wls_create(adf_wls_t** out, int use_confidence, int l, int r,
         if (gb > 0) h->ws_limit = (size_t)(gb * (double)((size_t)1 << 30));
     }
     if (const char* e = getenv("ADF_NO_OVERLAP")) h->overlap = atoi(e) == 0;   // measurement knob
+    if (const char* e = getenv("ADF_CONF_BAND")) h->conf_band = atoi(e) != 0;    // measurement knob
     *out = h;
     return ADF_OK;
 }
@@ -525,18 +527,24 @@ static int wls_filter_impl(adf_wls_t* h, int n_pairs,
                 // wave path: right map, then left map + LRC + x255 in one sweep (cL never hits memory);
                 // the first horizontal pass forms conf*disp itself when alignment allows
                 da.only_view = 1;
-                {
-                    ProfScope ps(prof, K_DISC, 2.0 * P, 6.0 * P, st);
-                    HIP_TRY(launch_discontinuity(da, n, st));              // DF.cpp:204 (right view)
-                }
                 fuse.conf_in = confp; fuse.conf_frame = g.frame; fuse.conf_pitch = W; fuse.conf_x0 = roi.x; fuse.conf_y0 = roi.y;
                 fuse.dl_in = dL; fuse.dl_stride = sL; fuse.dl_pair_stride = psL; fuse.dl_x0 = roi.x; fuse.dl_y0 = roi.y;
                 fuse.len = g.rw;
                 const bool fused_h = wave_hpass_can_fuse(fuse);
                 if (!fused_h) fuse = WavePassArgs{};
-                ConfLeftArgs ca{dL, sL, psL, dRp, sR, psR, cR, confp, fused_h ? nullptr : p.A0, fused_h ? nullptr : p.A1,
-                                g, rrx, thresh, h->disc_radius, h->roll_off};
-                {   // alg: conf (4P); moved: dL 2 + dR 2 + cR 4 reads, conf 4 (+8 when U0/U1 are materialised)
+                if (fused_h && h->conf_band && conf_band_fits(g, h->disc_radius)) {
+                    // both views, LRC and x255 in one band sweep: the right view's map lives in LDS only
+                    ConfBandArgs ba{dL, sL, psL, dRp, sR, psR, confp, g, rrx, thresh, h->disc_radius, h->roll_off, 0};
+                    ProfScope ps(prof, K_LRC, 8.0 * P, 8.0 * P, st);     // dL 2 + dR 2 read, conf 4 written
+                    HIP_TRY(launch_conf_band(ba, n, st));                  // DF.cpp:197-210
+                } else {
+                    {
+                        ProfScope ps(prof, K_DISC, 2.0 * P, 6.0 * P, st);
+                        HIP_TRY(launch_discontinuity(da, n, st));          // DF.cpp:204 (right view)
+                    }
+                    ConfLeftArgs ca{dL, sL, psL, dRp, sR, psR, cR, confp, fused_h ? nullptr : p.A0, fused_h ? nullptr : p.A1,
+                                    g, rrx, thresh, h->disc_radius, h->roll_off};
+                    // alg: conf (4P); moved: dL 2 + dR 2 + cR 4 reads, conf 4 (+8 when U0/U1 are materialised)
                     const double wu = fused_h ? 0.0 : 8.0;
                     ProfScope ps(prof, K_LRC, (4.0 + wu) * P, (12.0 + wu) * P, st);
                     HIP_TRY(launch_conf_left(ca, n, st));                  // DF.cpp:204-209 (+288-290)

@@ -63,6 +63,17 @@ struct ConfLeftArgs {
     int radius; float roll_off;
 };
 
+// Both views' discontinuity maps + LRC + x255 in ONE sweep over row bands (conf_band_kernel): the right view's
+// map of a row lives in LDS only, so nothing but dL, dR (read) and the confidence map (written) touches HBM.
+struct ConfBandArgs {
+    const int16_t* dL; ptrdiff_t sL, psL; // bytes
+    const int16_t* dR; ptrdiff_t sR, psR;
+    float* conf;                          // full-frame confidence (x255); only ROI pixels are written
+    Geom g; int rrx; int thresh;
+    int radius; float roll_off;
+    int rows_per_band;
+};
+
 // Non-ROI pixels: filtered map = fill (DF.cpp:284), confidence = 0 (DF.cpp:187-190); either may be null.
 struct OutsideArgs {
     int16_t* out; ptrdiff_t stride, pair_stride; int16_t fill;
@@ -150,6 +161,8 @@ hipError_t launch_discontinuity(const DiscArgs& a, int n_pairs, hipStream_t st);
 hipError_t launch_lrc_prologue(const LrcArgs& a, int n_pairs, hipStream_t st);
 hipError_t launch_conf_left(const ConfLeftArgs& a, int n_pairs, hipStream_t st); // radius <= 8 only
 hipError_t launch_outside(const OutsideArgs& a, int n_pairs, hipStream_t st);
+bool conf_band_fits(const Geom& g, int radius);                                 // geometry / radius the band kernel covers
+hipError_t launch_conf_band(const ConfBandArgs& a, int n_pairs, hipStream_t st);
 int conf_left_max_radius();
 hipError_t launch_plain_prologue(const PlainPrologueArgs& a, int n_pairs, hipStream_t st);
 hipError_t launch_weights(const WeightArgs& a, int n_pairs, hipStream_t st);

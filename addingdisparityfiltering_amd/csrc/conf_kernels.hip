@@ -346,6 +346,218 @@ __global__ void __launch_bounds__(NT) conf_left_kernel(ConfLeftArgs a)
     }
 }
 
+// ---------------------------------------------------------------------------------------
+// Both views in ONE sweep (DF.cpp:197-210 whole: 161-194 + 343-373 for both views, 306-341, :209): the right
+// view's discontinuity map never exists in HBM.  A workgroup owns a band of rows over the FULL ROI width; every
+// row step it forms the window statistics of both views, parks the right view's map of that row in LDS (16 KB
+// at 4K) together with the raw right disparities of the last few rows, and the left-view lanes gather from
+// there -- any column of the row, so the LRC is exact for arbitrary disparities without a fall-back path.
+// HBM sees dL and dR once (plus 2*RT halo rows per band) and the confidence map: 8 B per ROI pixel.
+//
+// Layout of the work: lane = 4 adjacent columns (one 8-byte load per view and row), wave = 64 lanes = 248
+// output columns (the first and last lane only supply the horizontal halo, so a wave never needs another
+// wave's sums).  Sums run VERTICAL first: each lane keeps the raw values of the last K = 2*RT+1 rows of its
+// columns packed in registers and updates the column sums (sum d, and sum d^2 split in 16-bit halves: all
+// 32-bit integer, exact) by new row minus oldest row; the horizontal window is then a sliding sum over the
+// lane's own four column sums and the neighbours' edge columns, fetched with whole-wave DPP shifts (no LDS, no
+// barrier).  Virtual columns: the row is extended by RT reflected columns on both sides (BORDER_REFLECT_101
+// inside the ROI copy, DF.cpp:167-185) and the lanes at the two image edges load the reflected real columns
+// (one 8-byte window + a byte permute), so the horizontal window itself never needs a border case.
+// One workgroup barrier per row (right map written -> gathered).
+// ---------------------------------------------------------------------------------------
+constexpr int CB_COLS = 4;
+constexpr int CB_WOUT = (64 - 2) * CB_COLS;   // output columns per wave
+constexpr int CB_MAX_WAVES = 16;
+
+__device__ __forceinline__ int dpp_from_prev(int v) { return __builtin_amdgcn_update_dpp(0, v, 0x138, 0xf, 0xf, false); }  // wave_shr:1
+__device__ __forceinline__ int dpp_from_next(int v) { return __builtin_amdgcn_update_dpp(0, v, 0x130, 0xf, 0xf, false); }  // wave_shl:1
+
+struct ColSum {
+    int s1, lo, hi;
+    // d enters / leaves the column window (exact: sum d, sum (d*d & 0xffff), sum (d*d >> 16))
+    __device__ __forceinline__ void slide(int dn, int dold)
+    {
+        const int qn = __mul24(dn, dn), qo = __mul24(dold, dold);
+        s1 += dn - dold;
+        lo += (qn & 0xffff) - (qo & 0xffff);
+        hi += (int)((unsigned)qn >> 16) - (int)((unsigned)qo >> 16);
+    }
+};
+
+__device__ __forceinline__ float disc_value(int s1, int lo, int hi, double scale, float roll_off)
+{
+    const float mean = (float)((double)s1 * scale);
+    const float sq = (float)(((double)hi * 65536.0 + (double)lo) * scale);
+    const float variance = sq - mean * mean;          // DF.cpp:369
+    const float v = 1.0f - roll_off * variance;       // DF.cpp:370
+    return v < 0.0f ? 0.0f : v;
+}
+
+// The four map values of a lane's columns from its column sums.  Horizontal window of output column q (0..3):
+// own columns max(0,q-RT) .. min(3,q+RT) -- differences of the lane's prefix sums -- plus the last RT-q columns of the
+// previous lane and the first q+RT-3 columns of the next one, each fetched as ONE partial sum by a whole-wave DPP shift
+// folded into the add that consumes it (every fetched value has a single use).
+template <int RT>
+__device__ __forceinline__ void band_row_values(const ColSum (&V)[CB_COLS], double scale, float roll_off, float (&out)[CB_COLS])
+{
+    static_assert(RT >= 1 && RT <= CB_COLS, "the halo must fit one lane");
+    int p1[CB_COLS + 1], pl[CB_COLS + 1], ph[CB_COLS + 1];           // prefix sums P[i] = V[0] + .. + V[i-1]
+    p1[0] = pl[0] = ph[0] = 0;
+#pragma unroll
+    for (int i = 0; i < CB_COLS; i++) { p1[i + 1] = p1[i] + V[i].s1; pl[i + 1] = pl[i] + V[i].lo; ph[i + 1] = ph[i] + V[i].hi; }
+#pragma unroll
+    for (int q = 0; q < CB_COLS; q++) {
+        const int a = q - RT > 0 ? q - RT : 0, b = (q + RT < CB_COLS - 1 ? q + RT : CB_COLS - 1) + 1;
+        int h1 = p1[b] - p1[a], hl = pl[b] - pl[a], hh = ph[b] - ph[a];
+        if (q < RT) {                                                // suffix of the previous lane: its last RT-q columns
+            const int m = RT - q;
+            h1 += dpp_from_prev(p1[CB_COLS] - p1[CB_COLS - m]); hl += dpp_from_prev(pl[CB_COLS] - pl[CB_COLS - m]);
+            hh += dpp_from_prev(ph[CB_COLS] - ph[CB_COLS - m]);
+        }
+        if (q + RT > CB_COLS - 1) {                                  // prefix of the next lane: its first q+RT-3 columns
+            const int m = q + RT - (CB_COLS - 1);
+            h1 += dpp_from_next(p1[m]); hl += dpp_from_next(pl[m]); hh += dpp_from_next(ph[m]);
+        }
+        out[q] = disc_value(h1, hl, hh, scale, roll_off);
+    }
+}
+
+template <int RT>
+__global__ void __launch_bounds__(64 * CB_MAX_WAVES) conf_band_kernel(ConfBandArgs a)
+{
+    constexpr int K = 2 * RT + 1;
+    constexpr int RING = RT + 2;                       // raw right rows kept in LDS (centre row + one row of slack for the slowest wave)
+    typedef int v2i_u __attribute__((ext_vector_type(2), aligned(2)));
+    typedef float v4f_u __attribute__((ext_vector_type(4), aligned(4)));
+    extern __shared__ __align__(16) unsigned char smem[];
+    const Geom& g = a.g;
+    const int rw = g.rw, rwp = (rw + 3) & ~3;
+    float* crow = reinterpret_cast<float*>(smem);                     // [2][rwp]   right map of the current row
+    int16_t* draw = reinterpret_cast<int16_t*>(crow + 2 * rwp);       // [RING][rwp] raw right disparities
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const size_t pz = blockIdx.y;
+    const int y0 = blockIdx.x * a.rows_per_band;
+    const int rows_out = min(a.rows_per_band, g.rh - y0);
+    const int nrows = rows_out + 2 * RT;               // input rows this band consumes
+    const int vbase = wv * CB_WOUT + CB_COLS * (lane - 1);            // first (virtual) column of this lane
+    const bool out_lane = lane >= 1 && lane <= 62 && vbase < rw;      // owns output columns vbase .. vbase+3 (those < rw)
+
+    // which real columns feed this lane's four virtual columns: one 8-byte window [lcol, lcol+4) of the row and a
+    // byte permute (identity for every lane away from the two image edges)
+    int lcol = vbase;
+    unsigned perm0 = 0x03020100u, perm1 = 0x07060504u;
+    if (!(vbase >= 0 && vbase + CB_COLS - 1 < rw)) {
+        int rv[CB_COLS], lo_need = rw;
+#pragma unroll
+        for (int q = 0; q < CB_COLS; q++) {
+            const int v = vbase + q;
+            const int vc = v < -RT ? -RT : (v > rw - 1 + RT ? rw - 1 + RT : v);
+            rv[q] = reflect101(vc, rw);
+            if (v >= -RT && v <= rw - 1 + RT) lo_need = min(lo_need, rv[q]);
+        }
+        lcol = lo_need >= rw ? 0 : lo_need;
+        lcol = max(0, min(lcol, rw - CB_COLS));
+        unsigned sb[CB_COLS];
+#pragma unroll
+        for (int q = 0; q < CB_COLS; q++) {
+            const unsigned e = (unsigned)max(0, min(rv[q] - lcol, CB_COLS - 1));
+            sb[q] = (2u * e) | ((2u * e + 1u) << 8);
+        }
+        perm0 = sb[0] | (sb[1] << 16);
+        perm1 = sb[2] | (sb[3] << 16);
+    }
+    // row base = wave-uniform (scalar registers), lane part = a 32-bit byte offset
+    const char* baseL = reinterpret_cast<const char*>(a.dL) + (ptrdiff_t)pz * a.psL + (ptrdiff_t)g.ry * a.sL + (ptrdiff_t)g.rx * 2;
+    const char* baseR = reinterpret_cast<const char*>(a.dR) + (ptrdiff_t)pz * a.psR + (ptrdiff_t)g.ry * a.sR + (ptrdiff_t)a.rrx * 2;
+    const unsigned lane_off = (unsigned)lcol * 2u;
+    float* conf = a.conf + pz * g.frame + (size_t)g.ry * g.W + g.rx;
+    const double scale = 1.0 / ((double)K * (double)K);
+    const int right_end = a.rrx + rw;
+
+    // packed raw rows: .x = columns (0,1), .y = columns (2,3) of the lane, 16 bits each
+    auto load = [&](const char* base, ptrdiff_t stride, int n) -> v2i_u {
+        const int nn = n < nrows ? n : nrows - 1;
+        int gy = abs(y0 - RT + nn);                                  // BORDER_REFLECT_101 with one reflection:
+        gy = gy >= g.rh ? 2 * (g.rh - 1) - gy : gy;                  // the launcher guarantees rh > RT
+        return *reinterpret_cast<const v2i_u*>(base + (ptrdiff_t)gy * stride + lane_off);
+    };
+    auto permute = [&](v2i_u p) -> int2 {
+        return make_int2((int)__builtin_amdgcn_perm((unsigned)p.y, (unsigned)p.x, perm0),
+                         (int)__builtin_amdgcn_perm((unsigned)p.y, (unsigned)p.x, perm1));
+    };
+#define CB_ELEM(P, q) ((q) == 0 ? (int)(short)((P).x & 0xffff) : (q) == 1 ? ((P).x >> 16) : (q) == 2 ? (int)(short)((P).y & 0xffff) : ((P).y >> 16))
+
+    int2 ringL[K], ringR[K];
+    ColSum VL[CB_COLS], VR[CB_COLS];
+#pragma unroll
+    for (int k = 0; k < K; k++) { ringL[k] = make_int2(0, 0); ringR[k] = make_int2(0, 0); }
+#pragma unroll
+    for (int q = 0; q < CB_COLS; q++) { VL[q].s1 = VL[q].lo = VL[q].hi = 0; VR[q].s1 = VR[q].lo = VR[q].hi = 0; }
+
+    // rows n+1 and n+2 are in flight while row n is reduced
+    v2i_u pfL0 = load(baseL, a.sL, 0), pfR0 = load(baseR, a.sR, 0);
+    v2i_u pfL1 = load(baseL, a.sL, 1), pfR1 = load(baseR, a.sR, 1);
+    for (int n0 = 0; n0 < nrows; n0 += K) {
+#pragma unroll
+        for (int s = 0; s < K; s++) {
+            const int n = n0 + s;
+            if (n < nrows) {                                             // block-uniform
+                const int2 curL = permute(pfL0), curR = permute(pfR0);
+                pfL0 = pfL1; pfR0 = pfR1;
+                pfL1 = load(baseL, a.sL, n + 2); pfR1 = load(baseR, a.sR, n + 2);
+                // vertical: row n enters the column windows, row n-K leaves (zeros during the first K rows)
+#pragma unroll
+                for (int q = 0; q < CB_COLS; q++) {
+                    VL[q].slide(CB_ELEM(curL, q), CB_ELEM(ringL[s], q));
+                    VR[q].slide(CB_ELEM(curR, q), CB_ELEM(ringR[s], q));
+                }
+                ringL[s] = curL; ringR[s] = curR;
+                float cl[CB_COLS], cr[CB_COLS];
+                const bool complete = n >= 2 * RT;                      // windows centred on input row n-RT are complete
+                if (complete) {                                          // (one basic block: the DPP fetches fold into their adds)
+                    band_row_values<RT>(VR, scale, a.roll_off, cr);
+                    band_row_values<RT>(VL, scale, a.roll_off, cl);
+                }
+                if (out_lane) {
+                    // raw right row n -> LDS (it is the centre row of the window that completes RT rows from now)
+                    *reinterpret_cast<int2*>(draw + (n % RING) * rwp + vbase) = curR;
+                    if (complete) *reinterpret_cast<float4*>(crow + (n & 1) * rwp + vbase) = make_float4(cr[0], cr[1], cr[2], cr[3]);
+                }
+                lds_barrier();
+                if (complete && out_lane) {
+                    const int oy = y0 + n - 2 * RT;                     // ROI row of the output
+                    const int2 cen = ringL[(s + K - RT) % K];            // the centre row's own disparities
+                    const float* cb = crow + (n & 1) * rwp;
+                    const int16_t* db = draw + ((n - RT) % RING) * rwp;
+                    float res[CB_COLS];
+#pragma unroll
+                    for (int q = 0; q < CB_COLS; q++) {
+                        const int d = CB_ELEM(cen, q);
+                        const int ridx = g.rx + vbase + q - (d >> 4);    // DF.cpp:331 (frame column of the right view)
+                        const bool hit = ridx >= a.rrx && ridx < right_end;  // DF.cpp:332
+                        const int rr = hit ? ridx - a.rrx : 0;           // (a miss reads column 0 and discards it)
+                        const float b = cb[rr];
+                        const int dr = db[rr];
+                        const float cmin = b < cl[q] ? b : cl[q];        // DF.cpp:334-335 (std::min)
+                        const float chit = abs(d + dr) < a.thresh ? cmin : 0.0f;   // DF.cpp:337
+                        res[q] = 255.0f * (hit ? chit : cl[q]);          // DF.cpp:209
+                    }
+                    float* dst = conf + (size_t)oy * g.W + vbase;
+                    if (vbase + CB_COLS <= rw) {
+                        const v4f_u o = {res[0], res[1], res[2], res[3]};
+                        __builtin_nontemporal_store(o, reinterpret_cast<v4f_u*>(dst));
+                    } else {
+#pragma unroll
+                        for (int q = 0; q < CB_COLS; q++)
+                            if (vbase + q < rw) ADF_ST(&dst[q], res[q]);
+                    }
+                }
+            }
+        }
+    }
+#undef CB_ELEM
+}
+
 constexpr int OUT_ROWS = 16; // rows per block of outside_kernel
 
 __global__ void __launch_bounds__(NT) outside_kernel(OutsideArgs a)
@@ -583,6 +795,44 @@ hipError_t launch_discontinuity(const DiscArgs& a, int n_pairs, hipStream_t st)
 }
 
 int conf_left_max_radius() { return 8; }
+
+static inline size_t conf_band_lds(int rw, int radius) { const size_t rwp = (size_t)((rw + 3) & ~3); return 2 * rwp * 4 + (size_t)(radius + 2) * rwp * 2; }
+
+bool conf_band_fits(const Geom& g, int radius)
+{
+    return radius >= 1 && radius <= 4 && g.rw >= 8 && g.rw <= CB_MAX_WAVES * CB_WOUT && g.rh > radius &&
+           conf_band_lds(g.rw, radius) <= 150 * 1024;
+}
+
+hipError_t launch_conf_band(const ConfBandArgs& a0, int n_pairs, hipStream_t st)
+{
+    if (!conf_band_fits(a0.g, a0.radius)) return hipErrorInvalidValue;
+    ConfBandArgs a = a0;
+    const int waves = (a.g.rw + CB_WOUT - 1) / CB_WOUT;
+    // bands: tall (the 2*RT halo rows and the K-row ramp are paid per band), but enough workgroups for two rounds
+    // of the chip's 256 CUs when the batch allows it
+    int bands = (512 + n_pairs - 1) / n_pairs;
+    int rpb = (a.g.rh + bands - 1) / bands;
+    if (rpb < 32) rpb = 32;
+    if (rpb > a.g.rh) rpb = a.g.rh;
+    a.rows_per_band = rpb;
+    const dim3 grid((a.g.rh + rpb - 1) / rpb, n_pairs), block(64 * waves);
+    const size_t lds = conf_band_lds(a.g.rw, a.radius);
+    static size_t configured[5] = {0, 0, 0, 0, 0};
+#define ADF_CB(RR)                                                                                          \
+    case RR:                                                                                                \
+        if (lds > 48 * 1024 && lds > configured[RR]) {                                                      \
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conf_band_kernel<RR>),         \
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);       \
+            if (e != hipSuccess) return e;                                                                  \
+            configured[RR] = lds;                                                                           \
+        }                                                                                                   \
+        hipLaunchKernelGGL(conf_band_kernel<RR>, grid, block, lds, st, a);                                  \
+        break;
+    switch (a.radius) { ADF_CB(1) ADF_CB(2) ADF_CB(3) ADF_CB(4) }
+#undef ADF_CB
+    return hipGetLastError();
+}
 
 hipError_t launch_conf_left(const ConfLeftArgs& a, int n_pairs, hipStream_t st)
 {

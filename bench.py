@@ -370,7 +370,11 @@ def worker(args):
         pipelined["hidden_transfer_ms"] = round(max(0.0, scatter_ms + gather_ms - pipelined["exposed_transfer_ms"]), 3)
     full = None
     checksum = parallel.sum_over_ranks(float(out.to(torch.int64).sum().item()), coll_dev)
-    checked_all = parallel.gather_objects(checked) if (world > 1 and checked is not None) else checked
+    # one flat list for the line: {"rank", "pair", ...} for the first and last pair of every rank
+    checked_all = None
+    if checked is not None:
+        per_rank = parallel.gather_objects(checked) if world > 1 else [checked]
+        checked_all = [dict(c, rank=r) for r, lst in enumerate(per_rank) for c in (lst or [])]
 
     if rank != 0:
         if world > 1:

@@ -32,7 +32,11 @@ def test_bench_line_contract():
     for key in ("value", "unit", "cores", "kind", "sample"):
         assert key in c, key
     assert c["kind"] in ("port", "reference") and c["value"] > 0 and c["cores"] >= 1
-    assert d["checked"]["confidence_bit_exact"] is True and d["checked"]["disparity_max_abs_lsb"] <= 1
-    v = d["views_to_filtered"]                       # extra leg: device matcher feeding the filter
+    assert [c["pair"] for c in d["checked"]] == [0, 3]           # first and last pair of the batch
+    for c in d["checked"]:
+        assert c["rank"] == 0 and c["confidence_bit_exact"] is True and c["disparity_max_abs_lsb"] <= 1
+    assert d["cpu_baseline"]["one_thread"]["scalar"] > 0 and d["cpu_baseline"]["one_thread"]["ref_simd"] > 0
+    assert d["roofline"]["traffic_source"] is None or "kernel_sources_sha16_now" in d["roofline"]["traffic_source"]
+    v = d["views_to_filtered"]["bm"]                 # extra leg: device matcher feeding the filter
     assert "error" not in v, v
     assert v["matcher_ms_per_pair"] > 0 and v["filter_ms_per_pair"] > 0 and v["num_disparities"] % 16 == 0
