@@ -32,6 +32,22 @@ class Params(C.Structure):
     ]
 
 
+class SGBMParams(C.Structure):
+    _fields_ = [
+        ("min_disparity", C.c_int),
+        ("num_disparities", C.c_int),
+        ("block_size", C.c_int),
+        ("P1", C.c_int),
+        ("P2", C.c_int),
+        ("prefilter_cap", C.c_int),
+        ("uniqueness_ratio", C.c_int),
+        ("mode", C.c_int),
+    ]
+
+
+SGBM_MODE_SGBM, SGBM_MODE_HH, SGBM_MODE_3WAY = 0, 1, 2
+
+
 class BMParams(C.Structure):
     _fields_ = [
         ("min_disparity", C.c_int),
@@ -45,7 +61,8 @@ class BMParams(C.Structure):
 
 def build(force=False):
     """Compile the oracle with gcc (oracle/Makefile)."""
-    src_m = max(os.path.getmtime(os.path.join(_HERE, f)) for f in ("adf_oracle.c", "adf_oracle_bm.c", "adf_oracle.h"))
+    src_m = max(os.path.getmtime(os.path.join(_HERE, f))
+                for f in ("adf_oracle.c", "adf_oracle_bm.c", "adf_oracle_sgbm.c", "adf_oracle.h"))
     if force or not os.path.exists(_LIB_PATH) or os.path.getmtime(_LIB_PATH) < src_m:
         subprocess.run(["make", "-C", _HERE, "-B", "libadf_oracle.so"], check=True,
                        stdout=subprocess.DEVNULL)
@@ -88,6 +105,12 @@ def lib():
         L.adf_oracle_bm_prefilter_xsobel.argtypes = [vp, pd, i, i, i, vp]
         L.adf_oracle_bm_compute.argtypes = [C.POINTER(BMParams), vp, pd, vp, pd, i, i, vp, pd]
         L.adf_oracle_bm_compute.restype = i
+        L.adf_oracle_sgbm_signals.argtypes = [vp, pd, i, i, i, i, vp]
+        L.adf_oracle_sgbm_block_costs.argtypes = [C.POINTER(SGBMParams), vp, pd, vp, pd, i, i, i, vp]
+        L.adf_oracle_sgbm_block_costs.restype = i
+        L.adf_oracle_sgbm_compute.argtypes = [C.POINTER(SGBMParams), vp, pd, vp, pd, i, i, i, vp, pd, vp]
+        L.adf_oracle_sgbm_compute.restype = i
+        L.adf_oracle_median3_16s.argtypes = [vp, pd, vp, pd, i, i]
         L.adf_oracle_set_refsimd_rowwise.argtypes = [i]
         L.adf_oracle_sat16.argtypes = [f]
         L.adf_oracle_sat16.restype = C.c_int16
@@ -289,4 +312,60 @@ def bm_compute(left, right, num_disparities, block_size, min_disparity=0, prefil
     rc = lib().adf_oracle_bm_compute(C.byref(prm), _p(left), left.strides[0], _p(right), right.strides[0], W, H, _p(out), W)
     if rc:
         raise ValueError("adf_oracle_bm_compute: bad arguments (%d)" % rc)
+    return out
+
+
+def _sgbm_images(img1, img2):
+    a = np.ascontiguousarray(img1, dtype=np.uint8)
+    b = np.ascontiguousarray(img2, dtype=np.uint8)
+    assert a.shape == b.shape and a.ndim in (2, 3)
+    cn = 1 if a.ndim == 2 else a.shape[2]
+    H, W = a.shape[:2]
+    return a, b, cn, W, H
+
+
+def sgbm_params(num_disparities, block_size, min_disparity=0, P1=0, P2=0, prefilter_cap=0, uniqueness_ratio=0,
+                mode=SGBM_MODE_3WAY):
+    return SGBMParams(min_disparity, num_disparities, block_size, P1, P2, prefilter_cap, uniqueness_ratio, mode)
+
+
+def sgbm_signals(img, prefilter_cap):
+    a = np.ascontiguousarray(img, dtype=np.uint8)
+    cn = 1 if a.ndim == 2 else a.shape[2]
+    H, W = a.shape[:2]
+    rec = np.empty((H, W, 2 * cn, 3), np.uint8)
+    lib().adf_oracle_sgbm_signals(_p(a), a.strides[0], cn, W, H, prefilter_cap, _p(rec))
+    return rec
+
+
+def sgbm_block_costs(img1, img2, prm):
+    """C[H][width1][D] of the whole image (small images only)."""
+    a, b, cn, W, H = _sgbm_images(img1, img2)
+    maxd = prm.min_disparity + prm.num_disparities
+    w1 = (W + min(prm.min_disparity, 0)) - max(maxd, 0)
+    out = np.zeros((H, max(w1, 0), prm.num_disparities), np.int16)
+    rc = lib().adf_oracle_sgbm_block_costs(C.byref(prm), _p(a), a.strides[0], _p(b), b.strides[0], cn, W, H, _p(out))
+    if rc:
+        raise ValueError("adf_oracle_sgbm_block_costs: bad arguments (%d)" % rc)
+    return out
+
+
+def sgbm_compute(img1, img2, num_disparities, block_size, min_disparity=0, P1=0, P2=0, prefilter_cap=0,
+                 uniqueness_ratio=0, mode=SGBM_MODE_3WAY, want_raw=False):
+    """Semi-global matcher restated from the published algorithm (adf_oracle_sgbm.c; parity unpinned)."""
+    a, b, cn, W, H = _sgbm_images(img1, img2)
+    prm = sgbm_params(num_disparities, block_size, min_disparity, P1, P2, prefilter_cap, uniqueness_ratio, mode)
+    out = np.empty((H, W), np.int16)
+    raw = np.empty((H, W), np.int16) if want_raw else None
+    rc = lib().adf_oracle_sgbm_compute(C.byref(prm), _p(a), a.strides[0], _p(b), b.strides[0], cn, W, H, _p(out), W,
+                                       None if raw is None else _p(raw))
+    if rc:
+        raise ValueError("adf_oracle_sgbm_compute: bad arguments (%d)" % rc)
+    return (out, raw) if want_raw else out
+
+
+def median3_16s(src):
+    s = np.ascontiguousarray(src, np.int16)
+    out = np.empty_like(s)
+    lib().adf_oracle_median3_16s(_p(s), s.shape[1], _p(out), s.shape[1], s.shape[1], s.shape[0])
     return out

@@ -156,6 +156,31 @@ int adf_oracle_bm_compute(const adf_oracle_bm_params* p, const uint8_t* left, pt
                           const uint8_t* right, ptrdiff_t rstride, int W, int H,
                           int16_t* disp, ptrdiff_t dstride);
 
+/* ---- semi-global matcher feeding the filter (adf_oracle_sgbm.c) ----
+ * cv::StereoSGBM is external to the reference (calib3d, unpinned): parity unpinned; see adf_oracle_sgbm.c. */
+#define ADF_SGBM_MODE_SGBM 0
+#define ADF_SGBM_MODE_HH 1
+#define ADF_SGBM_MODE_3WAY 2   /* StereoSGBM::MODE_SGBM_3WAY, the sample's mode (samples/disparity_filtering.cpp:170) */
+typedef struct adf_oracle_sgbm_params {
+    int min_disparity;      /* right matcher: -(min+num)+1, disparity_filters.cpp:435 */
+    int num_disparities;    /* multiple of 16 */
+    int block_size;         /* odd; 0 -> 5 */
+    int P1, P2;             /* sample: 24*w*w, 96*w*w; 0 -> 2 / 5; P2 >= P1+1 */
+    int prefilter_cap;      /* sample: 63 */
+    int uniqueness_ratio;   /* forced to 0 by the filter factory (disparity_filters.cpp:406,436); < 0 -> 10 */
+    int mode;               /* ADF_SGBM_MODE_3WAY only */
+} adf_oracle_sgbm_params;
+/* (value, min, max over the half-sample neighbours) of every signal of every pixel: rec[H][W][2cn][3] */
+void adf_oracle_sgbm_signals(const uint8_t* img, ptrdiff_t stride, int cn, int W, int H, int prefilter_cap, uint8_t* rec);
+/* block costs C[H][width1][D] of the whole image (width1 = matchable columns); small images, tests only */
+int adf_oracle_sgbm_block_costs(const adf_oracle_sgbm_params* p, const uint8_t* img1, ptrdiff_t s1, const uint8_t* img2,
+                                ptrdiff_t s2, int cn, int W, int H, int16_t* C);
+/* img1/img2: CV_8UC1 / CV_8UC3 W x H (strides in bytes); disp: CV_16SC1, stride in ELEMENTS; raw (nullable):
+ * the map before the 3x3 median, dense W x H. */
+int adf_oracle_sgbm_compute(const adf_oracle_sgbm_params* p, const uint8_t* img1, ptrdiff_t s1, const uint8_t* img2,
+                            ptrdiff_t s2, int cn, int W, int H, int16_t* disp, ptrdiff_t dstride, int16_t* raw);
+void adf_oracle_median3_16s(const int16_t* src, ptrdiff_t sstride, int16_t* dst, ptrdiff_t dstride, int W, int H);
+
 #ifdef __cplusplus
 }
 #endif

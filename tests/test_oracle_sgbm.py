@@ -1,0 +1,162 @@
+"""CPU tests of the semi-global matcher oracle (oracle/adf_oracle_sgbm.c).
+
+cv::StereoSGBM is external to the reference (parity unpinned at the calib3d boundary); the anchor the reference holds
+is its stereo module's semi-global test: the Tsukuba pair against testdata/groundtruth.bmp, 16 disparities, P1 = 10,
+P2 = 100, at most 10 % of the pixels off by more than 2*16 after the CV_16S map is scaled to 8 bits by
+255/(max-min) (modules/stereo/test/test_block_matching.cpp:157-238).  The three files are data under tests/golden/."""
+import numpy as np
+import pytest
+
+from test_oracle_bm import load_tsukuba
+
+SHRT_MAX = 32767
+
+
+def ref_error_level(gt, disp16):
+    """test_block_matching.cpp:218-231: convertTo(CV_8U, 255/(max-min)) then errorLevel (:61-82)."""
+    d = disp16.astype(np.float64)
+    t8 = np.clip(np.rint(d * 255.0 / (d.max() - d.min())), 0, 255).astype(np.int64)
+    bad = (gt != 0) & (np.abs(gt.astype(np.int64) - t8) > 2 * 16)
+    return 100.0 * bad.sum() / gt.size
+
+
+def naive_sgbm(img1, img2, nd, bs, md=0, P1=0, P2=0, cap=0, ur=0):
+    """Independent direct statement (numpy, whole cost volume in memory) of the definition in adf_oracle_sgbm.c."""
+    a = img1.astype(np.int64); b = img2.astype(np.int64)
+    if a.ndim == 2:
+        a = a[:, :, None]; b = b[:, :, None]
+    H, W, cn = a.shape
+    ftz = max(cap, 15) | 1
+    P1 = P1 if P1 > 0 else 2
+    P2 = max(P2 if P2 > 0 else 5, P1 + 1)
+
+    def signals(im):
+        up = np.concatenate([im[:1], im[:-1]]); dn = np.concatenate([im[1:], im[-1:]])
+        sig = np.full((H, W, 2 * cn), ftz, np.int64)
+        if W > 2:
+            g = (im[:, 2:] - im[:, :-2]) * 2 + up[:, 2:] - up[:, :-2] + dn[:, 2:] - dn[:, :-2]
+            sig[:, 1:-1, :cn] = np.clip(g, -ftz, ftz) + ftz
+            sig[:, 1:-1, cn:] = im[:, 1:-1]
+        left = np.concatenate([sig[:, :1], sig[:, :-1]], 1); right = np.concatenate([sig[:, 1:], sig[:, -1:]], 1)
+        vl = (sig + left) // 2; vr = (sig + right) // 2
+        vl[:, 0] = sig[:, 0]; vr[:, -1] = sig[:, -1]
+        return sig, np.minimum(np.minimum(vl, vr), sig), np.maximum(np.maximum(vl, vr), sig)
+
+    u, u0, u1 = signals(a); v, v0, v1 = signals(b)
+    maxd = md + nd
+    minx1 = max(maxd, 0); maxx1 = W + min(md, 0); w1 = maxx1 - minx1
+    out = np.full((H, W), (md - 1) * 16, np.int64)
+    if w1 <= 0:
+        return out
+    pix = np.zeros((H, w1, nd), np.int64)
+    xs = np.arange(minx1, maxx1)
+    for k in range(nd):
+        x2 = xs - (md + k)
+        c0 = np.maximum(np.maximum(0, u[:, xs] - v1[:, x2]), v0[:, x2] - u[:, xs])
+        c1 = np.maximum(np.maximum(0, v[:, x2] - u1[:, xs]), u0[:, xs] - v[:, x2])
+        m = np.minimum(c0, c1)
+        m[:, :, cn:] >>= 2
+        pix[:, :, k] = m.sum(2)
+    r = bs // 2
+    yy = np.clip(np.arange(-r, H + r), 0, H - 1); xx = np.clip(np.arange(-r, w1 + r), 0, w1 - 1)
+    Cv = np.zeros_like(pix)
+    for dy in range(bs):
+        for dx in range(bs):
+            Cv += pix[yy[dy:dy + H]][:, xx[dx:dx + w1]]
+    Cv = np.minimum(Cv, SHRT_MAX)
+
+    def step(Cp, Lp, mp):
+        big = np.array([SHRT_MAX])
+        lm = np.concatenate([big, Lp[:-1]]) + P1; lp = np.concatenate([Lp[1:], big]) + P1
+        L = Cp + np.minimum(np.minimum(Lp, lm), np.minimum(lp, mp + P2)) - mp
+        L = np.clip(L, -32768, SHRT_MAX)
+        return L, L.min()
+
+    Ltop = np.zeros((w1, nd), np.int64); mtop = np.zeros(w1, np.int64)
+    for y in range(H):
+        S = np.zeros((w1, nd), np.int64)
+        L = np.zeros(nd, np.int64); m = 0
+        for x in range(w1):
+            Ltop[x], mtop[x] = step(Cv[y, x], Ltop[x], mtop[x])
+            L, m = step(Cv[y, x], L, m)
+            S[x] = np.clip(L + Ltop[x], -32768, SHRT_MAX)
+        L = np.zeros(nd, np.int64); m = 0
+        for x in range(w1 - 1, -1, -1):
+            L, m = step(Cv[y, x], L, m)
+            Sp = np.clip(S[x] + L, -32768, SHRT_MAX)
+            best = int(np.argmin(Sp)); ms = int(Sp[best])            # argmin: first minimum
+            if ms >= SHRT_MAX:
+                continue
+            if ur > 0 and any(Sp[d] * (100 - ur) < ms * 100 and abs(best - d) > 1 for d in range(nd)):
+                continue
+            d = best
+            if 0 < d < nd - 1:
+                den = max(int(Sp[d - 1] + Sp[d + 1] - 2 * Sp[d]), 1)
+                num = int(Sp[d - 1] - Sp[d + 1]) * 16 + den
+                d = d * 16 + int(num / (den * 2))                    # C division truncates toward zero
+            else:
+                d *= 16
+            out[y, x + minx1] = d + md * 16
+    return out
+
+
+def naive_median3(a):
+    H, W = a.shape
+    p = np.pad(a, 1, mode="edge")
+    st = np.stack([p[dy:dy + H, dx:dx + W] for dy in range(3) for dx in range(3)])
+    return np.sort(st, 0)[4]
+
+
+def _pair(seed, H, W, cn=1, shift=3):
+    rng = np.random.default_rng(seed)
+    base = rng.integers(0, 256, (H, W + 40) + ((cn,) if cn > 1 else ()), dtype=np.uint8)
+    base = (base // 2 + np.roll(base, 1, 1) // 2).astype(np.uint8)
+    return np.ascontiguousarray(base[:, 20:20 + W]), np.ascontiguousarray(np.roll(base, -shift, 1)[:, 20:20 + W])
+
+
+@pytest.mark.parametrize("H,W,nd,bs,md,P1,P2,cap,ur,cn", [
+    (13, 40, 16, 3, 0, 72, 288, 63, 0, 1),       # the sample's setting for a 1-channel pair: P1 = 8*cn*w*w ... here 24*3, 96*3
+    (11, 37, 16, 5, 0, 0, 0, 0, 0, 1),           # every default (P1 2, P2 5, cap 15)
+    (12, 45, 16, 1, -15, 10, 100, 31, 0, 1),     # the right matcher's range (minDisparity = -(0+16)+1)
+    (10, 50, 32, 3, 2, 216, 864, 63, 15, 1),     # positive minimum disparity, uniqueness test on
+    (9, 33, 16, 7, -5, 50, 51, 20, 5, 1),        # range straddling zero, window taller than half the image
+    (8, 30, 16, 3, 0, 216, 864, 63, 0, 3),       # 3-channel views (the sample feeds colour images to SGBM)
+    (7, 20, 32, 3, 0, 10, 100, 63, 0, 1),        # search range wider than the image: everything invalid
+])
+def test_oracle_equals_direct_statement(oracle, H, W, nd, bs, md, P1, P2, cap, ur, cn):
+    a, b = _pair(H * W + nd, H, W, cn)
+    got, raw = oracle.sgbm_compute(a, b, nd, bs, md, P1, P2, cap, ur, want_raw=True)
+    exp_raw = naive_sgbm(a, b, nd, bs, md, P1, P2, cap, ur)
+    assert np.array_equal(raw, exp_raw)
+    assert np.array_equal(got, naive_median3(exp_raw))
+    if W - max(md + nd, 0) + min(md, 0) <= 0:
+        assert (raw == (md - 1) * 16).all()
+
+
+def test_block_costs_helper(oracle):
+    a, b = _pair(5, 12, 44)
+    prm = oracle.sgbm_params(16, 5, -3, prefilter_cap=40)
+    C = oracle.sgbm_block_costs(a, b, prm)
+    assert C.shape == (12, 44 - 13 - 3, 16) and C.min() >= 0 and C.max() > 0
+
+
+def test_reference_fixture_bar(oracle):
+    """test_block_matching.cpp:157-238 on the reference's own Tsukuba data: <= 10 % with its parameters (P1 10, P2 100,
+    uniqueness 1; its left-right check and speckle filter are post-filters this restatement does not have), and the
+    sample's parameters (disparity_filtering.cpp:166-170) do at least as well as the block matcher's 20 % bar."""
+    left, right, gt = load_tsukuba()
+    for bs in (5, 7, 9, 11):
+        d = oracle.sgbm_compute(left, right, 16, bs, 0, P1=10, P2=100, uniqueness_ratio=1)
+        assert ref_error_level(gt, d) <= 10.0, bs
+    d = oracle.sgbm_compute(left, right, 16, 3, 0, P1=24 * 9, P2=96 * 9, prefilter_cap=63)
+    assert ref_error_level(gt, d) <= 10.0
+    swapped = oracle.sgbm_compute(right, left, 16, 3, 0, P1=24 * 9, P2=96 * 9, prefilter_cap=63)
+    assert ref_error_level(gt, swapped) > 30.0            # the bar bites: views in the wrong order fail it
+
+
+def test_invalid_columns_and_range(oracle):
+    a, b = _pair(9, 20, 90, shift=4)
+    raw = oracle.sgbm_compute(a, b, 32, 3, 0, 72, 288, 63, want_raw=True)[1]
+    assert (raw[:, :32] == -16).all() and (raw[:, 32:] >= 0).all() and (raw[:, 32:] <= 31 * 16).all()
+    raw = oracle.sgbm_compute(b, a, 32, 3, -31, 72, 288, 63, want_raw=True)[1]      # createRightMatcher's range
+    assert (raw[:, 90 - 31:] == -32 * 16).all() and (raw[:, 1:90 - 31] <= 0).all() and (raw[:, 0] == -32 * 16).all()
