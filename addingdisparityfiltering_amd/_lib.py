@@ -88,6 +88,13 @@ SYMBOLS = [
     ("adf_bm_compute_device", _i, [_vp, _i, _vp, _pd, _pd, _vp, _pd, _pd, _i, _i, _vp, _pd, _pd, _vp]),
     ("adf_bm_compute_both_device", _i, [_vp, _i, _vp, _pd, _pd, _vp, _pd, _pd, _i, _i, _vp, _pd, _pd, _vp, _pd, _pd, _vp]),
     ("adf_bm_compute_host", _i, [_vp, _i, _vp, _pd, _pd, _vp, _pd, _pd, _i, _i, _vp, _pd, _pd]),
+    ("adf_sgbm_create", _i, [C.POINTER(_vp), _i, _i, _i]),
+    ("adf_sgbm_destroy", None, [_vp]),
+    ("adf_sgbm_get_device", _i, [_vp, C.POINTER(_i)]),
+    ("adf_sgbm_set_params", _i, [_vp] + [_i] * 8),
+    ("adf_sgbm_get_params", _i, [_vp] + [C.POINTER(_i)] * 8),
+    ("adf_sgbm_compute_device", _i, [_vp, _i, _vp, _pd, _pd, _vp, _pd, _pd, _i, _i, _i, _vp, _pd, _pd, _vp]),
+    ("adf_sgbm_compute_host", _i, [_vp, _i, _vp, _pd, _pd, _vp, _pd, _pd, _i, _i, _i, _vp, _pd, _pd]),
 ]
 
 _lib = None

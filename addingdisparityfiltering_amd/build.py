@@ -15,6 +15,7 @@ SOURCES = {
     "eval_kernels.hip": [],
     "resize_kernels.hip": [],
     "bm_matcher.hip": [],
+    "sgbm_matcher.hip": [],
 }
 HEADERS = ["adf_internal.h", "fgs_wave_common.h"]
 OUT = os.path.join(_HERE, "libadf_wls.so")

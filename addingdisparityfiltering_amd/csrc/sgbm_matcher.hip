@@ -1,0 +1,565 @@
+// sgbm_matcher.hip -- semi-global matcher on the device (second producer).
+//
+// The reference's sample feeds the filter from cv::StereoSGBM with MODE_SGBM_3WAY
+// (samples/disparity_filtering.cpp:166-176); the filter factories only touch its parameters
+// (disparity_filters.cpp:404-409, 432-445).  cv::StereoSGBM lives in OpenCV's calib3d, outside the reference tree:
+// PARITY UNPINNED there.  What is built is the published algorithm (Hirschmueller 2008, formula 13, three paths,
+// Birchfield-Tomasi block cost) exactly as oracle/adf_oracle_sgbm.c states it -- integer work, bit-identical to that
+// oracle -- with the in-tree derivative of OpenCV's aggregation loop (modules/stereo/src/stereo_binary_sgbm.cpp) as
+// the line-cited anchor of the recurrence, the winner / tie rule, the uniqueness test and the sub-pixel fit.
+//
+// Five kernels per call, all integer, none with a dense contraction (no MFMA):
+//   sgbm_signals_kernel   per pixel and channel: clipped x-derivative + intensity, each with the extrema over its
+//                         half-sample neighbours, packed as 16-bit pairs (derivative | intensity) so that one packed
+//                         instruction serves both Birchfield-Tomasi terms
+//   sgbm_cost_kernel      block cost volume C[y][x][d] (int16): one workgroup = one matchable column x, one thread =
+//                         one disparity, walking down a band of rows with the horizontal window summed directly and
+//                         the vertical window as a running sum over a register ring (stereo_binary_sgbm.cpp:205-276)
+//   sgbm_path_kernel      formula 13 along one direction, one wavefront per scanline, the D path costs of a pixel held
+//                         4 (2, 1, 8) per lane; d-1 / d+1 across lanes by whole-wave DPP shifts, min_k by a DPP
+//                         butterfly + 4 readlanes.  TOP writes the volume S, LEFT adds to it, RIGHT adds, picks the
+//                         winner and fits the sub-pixel parabola (stereo_binary_sgbm.cpp:286-301, 419-446, 519-596)
+//   sgbm_fill_kernel / sgbm_median_kernel   invalid value everywhere first; 3x3 median of the CV_16S map last
+// HBM: C and S volumes of H x width1 x D int16 each (4K, 256 disparities: 4 GB each, per image in flight).
+#include "adf_internal.h"
+#include "../../include/adf_wls.h"
+
+#include <algorithm>
+#include <cstdlib>
+#include <new>
+
+namespace {
+
+constexpr int SG_MAX_COST = 32767;   // SHRT_MAX: guard value of the d = -1 / d = D neighbours (stereo_binary_sgbm.cpp:323-324)
+constexpr int SG_DISP_SHIFT = 4, SG_DISP_SCALE = 16;
+
+typedef unsigned short us2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ int sat16i(int v) { return v < -32768 ? -32768 : (v > 32767 ? 32767 : v); }
+
+// ---------------------------------------------------------------------------------------------------------------
+// signals: rec[(y*W + x)*cn + c] = {V, V0, V1}, each (derivative | intensity << 16) of channel c
+// ---------------------------------------------------------------------------------------------------------------
+struct SignalArgs {
+    const uint8_t* img; ptrdiff_t stride, pair_stride; int cn, W, H, ftzero;
+    uint32_t* rec; size_t rec_pair;     // dwords per image
+};
+
+__device__ __forceinline__ uint32_t sg_signal(const uint8_t* row, const uint8_t* up, const uint8_t* dn, int x, int c, int cn, int W, int ftzero)
+{
+    if (x <= 0 || x >= W - 1) return (uint32_t)ftzero | ((uint32_t)ftzero << 16);     // border columns hold ftzero
+    const int a = x * cn + c;
+    int g = (row[a + cn] - row[a - cn]) * 2 + up[a + cn] - up[a - cn] + dn[a + cn] - dn[a - cn];
+    g = min(max(g, -ftzero), ftzero) + ftzero;
+    return (uint32_t)g | ((uint32_t)row[a] << 16);
+}
+
+__global__ void __launch_bounds__(256) sgbm_signals_kernel(SignalArgs a)
+{
+    const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
+    if (x >= a.W) return;
+    const uint8_t* row = a.img + (ptrdiff_t)blockIdx.z * a.pair_stride + (ptrdiff_t)y * a.stride;
+    const uint8_t* up = y > 0 ? row - a.stride : row;
+    const uint8_t* dn = y < a.H - 1 ? row + a.stride : row;
+    uint32_t* o = a.rec + (size_t)blockIdx.z * a.rec_pair + ((size_t)y * a.W + x) * a.cn * 3;
+    for (int c = 0; c < a.cn; c++) {
+        const uint32_t v = sg_signal(row, up, dn, x, c, a.cn, a.W, a.ftzero);
+        const uint32_t l = sg_signal(row, up, dn, x - 1, c, a.cn, a.W, a.ftzero);
+        const uint32_t r = sg_signal(row, up, dn, x + 1, c, a.cn, a.W, a.ftzero);
+        uint32_t out0 = 0, out1 = 0;
+#pragma unroll
+        for (int h = 0; h < 2; h++) {                          // the two signals of the pair
+            const int vv = (v >> (16 * h)) & 0xffff, ll = (l >> (16 * h)) & 0xffff, rr = (r >> (16 * h)) & 0xffff;
+            const int vl = x > 0 ? (vv + ll) / 2 : vv;
+            const int vr = x < a.W - 1 ? (vv + rr) / 2 : vv;
+            out0 |= (uint32_t)min(min(vl, vr), vv) << (16 * h);
+            out1 |= (uint32_t)max(max(vl, vr), vv) << (16 * h);
+        }
+        o[c * 3 + 0] = v; o[c * 3 + 1] = out0; o[c * 3 + 2] = out1;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// block costs
+// ---------------------------------------------------------------------------------------------------------------
+struct CostArgs {
+    const uint32_t* rec1; const uint32_t* rec2; size_t rec_pair;
+    int16_t* C; size_t vol;              // int16 elements per image volume = H * w1 * D
+    int W, H, D, minD, minX1, w1, rows_per_band;
+};
+
+struct Rec { uint32_t v, v0, v1; };
+
+// Birchfield-Tomasi cost of the pair of signals: distance of u to [v0, v1] and of v to [u0, u1], the smaller one, as
+// saturating 16-bit pairs (v0 <= v1, so at most one of the two differences of a distance is non-zero); the intensity
+// half is scaled by 1/4 before the terms are summed.
+__device__ __forceinline__ us2 bt_pair(const Rec& u, const Rec& v)
+{
+    const us2 U = __builtin_bit_cast(us2, u.v), U0 = __builtin_bit_cast(us2, u.v0), U1 = __builtin_bit_cast(us2, u.v1);
+    const us2 V = __builtin_bit_cast(us2, v.v), V0 = __builtin_bit_cast(us2, v.v0), V1 = __builtin_bit_cast(us2, v.v1);
+    const us2 c0 = __builtin_elementwise_sub_sat(V0, U) | __builtin_elementwise_sub_sat(U, V1);
+    const us2 c1 = __builtin_elementwise_sub_sat(U0, V) | __builtin_elementwise_sub_sat(V, U1);
+    const us2 m = __builtin_elementwise_min(c0, c1);
+    const us2 sh = {0, 2};
+    return m >> sh;
+}
+
+template <int BS, int CN>
+__global__ void __launch_bounds__(512) sgbm_cost_kernel(CostArgs a)
+{
+    constexpr int R = BS / 2;
+    const int x1 = blockIdx.x, d = threadIdx.x;
+    if (d >= a.D) return;
+    const int y0 = blockIdx.y * a.rows_per_band;
+    const int rows_out = min(a.rows_per_band, a.H - y0);
+    const uint32_t* rec1 = a.rec1 + (size_t)blockIdx.z * a.rec_pair;
+    const uint32_t* rec2 = a.rec2 + (size_t)blockIdx.z * a.rec_pair;
+    int16_t* C = a.C + (size_t)blockIdx.z * a.vol;
+    int ring[BS], csum = 0;
+#pragma unroll
+    for (int k = 0; k < BS; k++) ring[k] = 0;
+    // columns of the horizontal window, clamped inside the matchable area (image columns)
+    int xu[BS];
+#pragma unroll
+    for (int j = 0; j < BS; j++) xu[j] = a.minX1 + min(max(x1 + j - R, 0), a.w1 - 1);
+    const int nsteps = rows_out + BS - 1;
+    for (int n0 = 0; n0 < nsteps; n0 += BS) {
+#pragma unroll
+        for (int s = 0; s < BS; s++) {
+            const int n = n0 + s;
+            if (n < nsteps) {                                    // block-uniform
+                const int yy = min(max(y0 - R + n, 0), a.H - 1);
+                us2 acc = {0, 0};
+#pragma unroll
+                for (int j = 0; j < BS; j++) {
+                    const uint32_t* pu = rec1 + ((size_t)yy * a.W + xu[j]) * (CN * 3);                       // uniform
+                    const uint32_t* pv = rec2 + ((size_t)yy * a.W + (xu[j] - (d + a.minD))) * (CN * 3);      // per lane
+#pragma unroll
+                    for (int c = 0; c < CN; c++) {
+                        const Rec u = {pu[c * 3], pu[c * 3 + 1], pu[c * 3 + 2]};
+                        const Rec v = {pv[c * 3], pv[c * 3 + 1], pv[c * 3 + 2]};
+                        acc += bt_pair(u, v);
+                    }
+                }
+                const int hs = (int)acc.x + (int)acc.y;           // horizontal window sum of row yy
+                csum += hs - ring[s];
+                ring[s] = hs;
+                if (n >= BS - 1) {
+                    const int y = y0 + n - (BS - 1);
+                    C[((size_t)y * a.w1 + x1) * a.D + d] = (int16_t)min(csum, SG_MAX_COST);
+                }
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// path costs
+// ---------------------------------------------------------------------------------------------------------------
+enum { DIR_TOP = 0, DIR_LEFT = 1, DIR_RIGHT = 2 };
+
+struct PathArgs {
+    const int16_t* C; int16_t* S; size_t vol;
+    int W, H, D, minD, minX1, w1, P1, P2, ur;
+    int16_t* out; ptrdiff_t out_stride, out_pair;   // raw disparity map (elements)
+};
+
+__device__ __forceinline__ int wave_min_i32(int v)
+{
+    // min is idempotent: rotations by 1, 2, 4, 8 inside each row of 16 lanes leave the row minimum in every lane
+    v = min(v, __builtin_amdgcn_update_dpp(v, v, 0x121, 0xf, 0xf, false));   // row_ror:1
+    v = min(v, __builtin_amdgcn_update_dpp(v, v, 0x122, 0xf, 0xf, false));   // row_ror:2
+    v = min(v, __builtin_amdgcn_update_dpp(v, v, 0x124, 0xf, 0xf, false));   // row_ror:4
+    v = min(v, __builtin_amdgcn_update_dpp(v, v, 0x128, 0xf, 0xf, false));   // row_ror:8
+    const int a = __builtin_amdgcn_readlane(v, 0), b = __builtin_amdgcn_readlane(v, 16);
+    const int c = __builtin_amdgcn_readlane(v, 32), e = __builtin_amdgcn_readlane(v, 48);
+    return min(min(a, b), min(c, e));
+}
+
+template <int DPL> struct Vec16 { int16_t v[DPL]; };
+
+template <int DPL>
+__device__ __forceinline__ void load_costs(const int16_t* p, bool active, int (&o)[DPL])
+{
+    // a lane's DPL disparities are all inside [0, D) or all outside (D is a multiple of 16, DPL divides 16)
+    typedef short vs __attribute__((ext_vector_type(DPL)));
+    if (active) {
+        if constexpr (DPL == 1) o[0] = p[0];
+        else {
+            const vs q = *reinterpret_cast<const vs*>(p);
+#pragma unroll
+            for (int k = 0; k < DPL; k++) o[k] = q[k];
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < DPL; k++) o[k] = 0;
+    }
+}
+
+template <int DPL>
+__device__ __forceinline__ void store_costs(int16_t* p, bool active, const int (&v)[DPL])
+{
+    typedef short vs __attribute__((ext_vector_type(DPL)));
+    if (!active) return;
+    if constexpr (DPL == 1) p[0] = (int16_t)v[0];
+    else {
+        vs q;
+#pragma unroll
+        for (int k = 0; k < DPL; k++) q[k] = (short)v[k];
+        *reinterpret_cast<vs*>(p) = q;
+    }
+}
+
+template <int DPL, int DIR>
+__global__ void __launch_bounds__(256) sgbm_path_kernel(PathArgs a)
+{
+    __shared__ int16_t sS[4][64 * DPL];                       // DIR_RIGHT: the pixel's S(d) for the sub-pixel fit
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int line = blockIdx.x * 4 + wv;                     // scanline: column (TOP) or row (LEFT / RIGHT)
+    const int nlines = DIR == DIR_TOP ? a.w1 : a.H;
+    if (line >= nlines) return;
+    const int nsteps = DIR == DIR_TOP ? a.H : a.w1;
+    const int d0 = lane * DPL;
+    const bool active = d0 < a.D;
+    const size_t vol0 = (size_t)blockIdx.y * a.vol;
+    const int16_t* C = a.C + vol0 + d0;
+    int16_t* S = a.S + vol0 + d0;
+    // element offset of step t
+    auto offs = [&](int t) -> size_t {
+        if (DIR == DIR_TOP) return ((size_t)t * a.w1 + line) * a.D;
+        const int x = DIR == DIR_LEFT ? t : a.w1 - 1 - t;
+        return ((size_t)line * a.w1 + x) * a.D;
+    };
+    int L[DPL];
+#pragma unroll
+    for (int k = 0; k < DPL; k++) L[k] = active ? 0 : SG_MAX_COST;      // zero start (stereo_binary_sgbm.cpp:191-194)
+    int minprev = 0;
+    int cnext[DPL], snext[DPL];
+    load_costs<DPL>(C + offs(0), active, cnext);
+    if (DIR != DIR_TOP) load_costs<DPL>(S + offs(0), active, snext);
+    int16_t* out = DIR == DIR_RIGHT ? a.out + (ptrdiff_t)blockIdx.y * a.out_pair + (ptrdiff_t)line * a.out_stride : nullptr;
+    for (int t = 0; t < nsteps; t++) {
+        int c[DPL], s[DPL];
+#pragma unroll
+        for (int k = 0; k < DPL; k++) { c[k] = cnext[k]; s[k] = DIR != DIR_TOP ? snext[k] : 0; }
+        const size_t o = offs(t);
+        if (t + 1 < nsteps) {                                  // next step's operands are in flight during this one
+            load_costs<DPL>(C + offs(t + 1), active, cnext);
+            if (DIR != DIR_TOP) load_costs<DPL>(S + offs(t + 1), active, snext);
+        }
+        // formula 13 (stereo_binary_sgbm.cpp:419-446): neighbours d-1 / d+1, guards SHRT_MAX outside [0, D)
+        const int lm = __builtin_amdgcn_update_dpp(SG_MAX_COST, L[DPL - 1], 0x138, 0xf, 0xf, false);   // wave_shr:1
+        const int lp = __builtin_amdgcn_update_dpp(SG_MAX_COST, L[0], 0x130, 0xf, 0xf, false);         // wave_shl:1
+        const int delta = minprev + a.P2;
+        int Ln[DPL], lmin = SG_MAX_COST;
+#pragma unroll
+        for (int k = 0; k < DPL; k++) {
+            const int below = k == 0 ? lm : L[k - 1], above = k == DPL - 1 ? lp : L[k + 1];
+            const int m = min(min(L[k], below + a.P1), min(above + a.P1, delta));
+            Ln[k] = active ? sat16i(c[k] + m - minprev) : SG_MAX_COST;
+            lmin = min(lmin, Ln[k]);
+        }
+#pragma unroll
+        for (int k = 0; k < DPL; k++) L[k] = Ln[k];
+        minprev = wave_min_i32(lmin);
+        if (DIR == DIR_TOP) {
+            store_costs<DPL>(S + o, active, Ln);
+        } else {
+            int st[DPL];
+#pragma unroll
+            for (int k = 0; k < DPL; k++) st[k] = sat16i(s[k] + Ln[k]);
+            if (DIR == DIR_LEFT) {
+                store_costs<DPL>(S + o, active, st);
+            } else {
+                // winner: the FIRST disparity with the smallest S (stereo_binary_sgbm.cpp:519-528)
+                int bv = SG_MAX_COST, bk = 0;
+#pragma unroll
+                for (int k = 0; k < DPL; k++) if (active && st[k] < bv) { bv = st[k]; bk = k; }
+                const int minS = wave_min_i32(bv);
+                const int best = wave_min_i32((active && bv == minS) ? d0 + bk : (1 << 20));
+                bool reject = false;
+                if (a.ur > 0) {                                // stereo_binary_sgbm.cpp:543-547
+#pragma unroll
+                    for (int k = 0; k < DPL; k++)
+                        reject |= active && st[k] * (100 - a.ur) < minS * 100 && abs(best - (d0 + k)) > 1;
+                }
+                const bool any_reject = __builtin_amdgcn_ballot_w64(reject) != 0;
+                store_costs<DPL>(&sS[wv][d0], active, st);
+                if (minS < SG_MAX_COST && !any_reject && lane == 0) {
+                    int d = best;
+                    if (0 < d && d < a.D - 1) {                // stereo_binary_sgbm.cpp:584-591
+                        const int sm = sS[wv][d - 1], s0 = sS[wv][d], sp = sS[wv][d + 1];
+                        const int denom2 = max(sm + sp - 2 * s0, 1);
+                        d = d * SG_DISP_SCALE + ((sm - sp) * SG_DISP_SCALE + denom2) / (denom2 * 2);
+                    } else
+                        d *= SG_DISP_SCALE;
+                    out[a.minX1 + (a.w1 - 1 - t)] = (int16_t)(d + a.minD * SG_DISP_SCALE);   // :596
+                }
+            }
+        }
+    }
+}
+
+struct FillArgs { int16_t* p; ptrdiff_t stride, pair; int W, H; int16_t v; };
+__global__ void __launch_bounds__(256) sgbm_fill_kernel(FillArgs a)
+{
+    const int x = blockIdx.x * 256 + threadIdx.x;
+    if (x < a.W) a.p[(ptrdiff_t)blockIdx.z * a.pair + (ptrdiff_t)blockIdx.y * a.stride + x] = a.v;
+}
+
+struct MedianArgs { const int16_t* src; ptrdiff_t sstride, spair; int16_t* dst; ptrdiff_t dstride, dpair; int W, H; };
+__device__ __forceinline__ void cswap(int& a, int& b) { const int lo = min(a, b), hi = max(a, b); a = lo; b = hi; }
+__global__ void __launch_bounds__(256) sgbm_median_kernel(MedianArgs a)
+{
+    const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
+    if (x >= a.W) return;
+    const int16_t* s = a.src + (ptrdiff_t)blockIdx.z * a.spair;
+    int v[9];
+#pragma unroll
+    for (int dy = -1; dy <= 1; dy++)
+#pragma unroll
+        for (int dx = -1; dx <= 1; dx++)
+            v[(dy + 1) * 3 + dx + 1] = s[(ptrdiff_t)min(max(y + dy, 0), a.H - 1) * a.sstride + min(max(x + dx, 0), a.W - 1)];
+    // median of nine by the classic 19-exchange network
+    cswap(v[1], v[2]); cswap(v[4], v[5]); cswap(v[7], v[8]); cswap(v[0], v[1]); cswap(v[3], v[4]); cswap(v[6], v[7]);
+    cswap(v[1], v[2]); cswap(v[4], v[5]); cswap(v[7], v[8]); cswap(v[0], v[3]); cswap(v[5], v[8]); cswap(v[4], v[7]);
+    cswap(v[3], v[6]); cswap(v[1], v[4]); cswap(v[2], v[5]); cswap(v[4], v[7]); cswap(v[4], v[2]); cswap(v[6], v[4]);
+    cswap(v[4], v[2]);
+    a.dst[(ptrdiff_t)blockIdx.z * a.dpair + (ptrdiff_t)y * a.dstride + x] = (int16_t)v[4];
+}
+
+int sg_fail(int code, const char* msg) { return adf::set_error(code, msg); }
+
+struct DevScope {
+    int prev = -1; bool sw = false;
+    explicit DevScope(int d) { if (hipGetDevice(&prev) == hipSuccess && prev != d) sw = hipSetDevice(d) == hipSuccess; }
+    ~DevScope() { if (sw) hipSetDevice(prev); }
+};
+
+int sg_reserve(void** p, size_t* have, size_t need, hipStream_t st)
+{
+    if (need <= *have) return ADF_OK;
+    if (*p) { if (hipStreamSynchronize(st) != hipSuccess) return sg_fail(ADF_EHIP, "hipStreamSynchronize failed"); hipFree(*p); *p = nullptr; *have = 0; }
+    need = (need + 255) / 256 * 256;
+    hipError_t e = hipMalloc(p, need);
+    if (e != hipSuccess) { *p = nullptr; return sg_fail(e == hipErrorOutOfMemory ? ADF_ENOMEM : ADF_EHIP, "hipMalloc failed for the matcher workspace"); }
+    *have = need;
+    return ADF_OK;
+}
+
+template <int CN>
+hipError_t launch_cost(const CostArgs& a, int bs, dim3 grid, dim3 block, hipStream_t st)
+{
+    switch (bs) {
+    case 1: hipLaunchKernelGGL((sgbm_cost_kernel<1, CN>), grid, block, 0, st, a); break;
+    case 3: hipLaunchKernelGGL((sgbm_cost_kernel<3, CN>), grid, block, 0, st, a); break;
+    case 5: hipLaunchKernelGGL((sgbm_cost_kernel<5, CN>), grid, block, 0, st, a); break;
+    case 7: hipLaunchKernelGGL((sgbm_cost_kernel<7, CN>), grid, block, 0, st, a); break;
+    case 9: hipLaunchKernelGGL((sgbm_cost_kernel<9, CN>), grid, block, 0, st, a); break;
+    case 11: hipLaunchKernelGGL((sgbm_cost_kernel<11, CN>), grid, block, 0, st, a); break;
+    default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
+
+template <int DPL>
+hipError_t launch_paths(const PathArgs& a, int n, hipStream_t st)
+{
+    hipLaunchKernelGGL((sgbm_path_kernel<DPL, DIR_TOP>), dim3((a.w1 + 3) / 4, n), dim3(256), 0, st, a);
+    hipLaunchKernelGGL((sgbm_path_kernel<DPL, DIR_LEFT>), dim3((a.H + 3) / 4, n), dim3(256), 0, st, a);
+    hipLaunchKernelGGL((sgbm_path_kernel<DPL, DIR_RIGHT>), dim3((a.H + 3) / 4, n), dim3(256), 0, st, a);
+    return hipGetLastError();
+}
+
+} // namespace
+
+// ----------------------------------------------------------------------------------------------
+// C-ABI (include/adf_wls.h, "semi-global matcher")
+// ----------------------------------------------------------------------------------------------
+struct adf_sgbm {
+    int device = 0;
+    int min_disp = 0, num_disp = 16, block = 3;
+    int P1 = 0, P2 = 0, cap = 0, uniq = 10, mode = ADF_SGBM_MODE_SGBM;   // cv::StereoSGBM::create's defaults
+    void* ws = nullptr; size_t ws_bytes = 0;
+    void* stage = nullptr; size_t stage_bytes = 0;
+    size_t ws_limit = (size_t)64 << 30;
+};
+
+extern "C" int adf_sgbm_create(adf_sgbm_t** out, int min_disparity, int num_disparities, int block_size)
+{
+    if (!out) return sg_fail(ADF_EBADARG, "out is NULL");
+    *out = nullptr;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return sg_fail(ADF_ENODEV, "no HIP device");
+    adf_sgbm* h = new (std::nothrow) adf_sgbm;
+    if (!h) return sg_fail(ADF_ENOMEM, "out of host memory");
+    h->device = dev; h->min_disp = min_disparity; h->num_disp = num_disparities; h->block = block_size;
+    if (const char* e = getenv("ADF_WS_LIMIT_GB")) {
+        const double gb = atof(e);
+        if (gb > 0) h->ws_limit = (size_t)(gb * (double)((size_t)1 << 30));
+    }
+    *out = h;
+    return ADF_OK;
+}
+
+extern "C" void adf_sgbm_destroy(adf_sgbm_t* h)
+{
+    if (!h) return;
+    DevScope ds(h->device);
+    if (h->ws) hipFree(h->ws);
+    if (h->stage) hipFree(h->stage);
+    delete h;
+}
+
+extern "C" int adf_sgbm_set_params(adf_sgbm_t* h, int min_disparity, int num_disparities, int block_size, int P1, int P2,
+                                   int prefilter_cap, int uniqueness_ratio, int mode)
+{
+    if (!h) return sg_fail(ADF_EBADARG, "handle is NULL");
+    h->min_disp = min_disparity; h->num_disp = num_disparities; h->block = block_size;
+    h->P1 = P1; h->P2 = P2; h->cap = prefilter_cap; h->uniq = uniqueness_ratio; h->mode = mode;
+    return ADF_OK;
+}
+
+extern "C" int adf_sgbm_get_params(const adf_sgbm_t* h, int* min_disparity, int* num_disparities, int* block_size, int* P1, int* P2,
+                                   int* prefilter_cap, int* uniqueness_ratio, int* mode)
+{
+    if (!h) return sg_fail(ADF_EBADARG, "handle is NULL");
+    if (min_disparity) *min_disparity = h->min_disp;
+    if (num_disparities) *num_disparities = h->num_disp;
+    if (block_size) *block_size = h->block;
+    if (P1) *P1 = h->P1;
+    if (P2) *P2 = h->P2;
+    if (prefilter_cap) *prefilter_cap = h->cap;
+    if (uniqueness_ratio) *uniqueness_ratio = h->uniq;
+    if (mode) *mode = h->mode;
+    return ADF_OK;
+}
+
+extern "C" int adf_sgbm_get_device(const adf_sgbm_t* h, int* device)
+{
+    if (!h) return sg_fail(ADF_EBADARG, "handle is NULL");
+    if (device) *device = h->device;
+    return ADF_OK;
+}
+
+static int sgbm_check(const adf_sgbm* h, int n, const void* l, const void* r, const void* d, int cn, int W, int H,
+                      ptrdiff_t ls, ptrdiff_t rs, ptrdiff_t dstr)
+{
+    if (!h) return sg_fail(ADF_EBADARG, "handle is NULL");
+    if (n <= 0 || !l || !r || !d) return sg_fail(ADF_EBADARG, "views and disparity must be non-NULL, n_pairs positive");
+    if (cn != 1 && cn != 3) return sg_fail(ADF_EBADARG, "views must be CV_8UC1 or CV_8UC3");
+    if (W <= 0 || H <= 0 || ls < (ptrdiff_t)W * cn || rs < (ptrdiff_t)W * cn || dstr < (ptrdiff_t)W * 2) return sg_fail(ADF_ESIZE, "bad size or stride");
+    if ((dstr & 1) || (reinterpret_cast<uintptr_t>(d) & 1)) return sg_fail(ADF_ESIZE, "disparity rows must be 2-byte aligned");
+    if (h->mode != ADF_SGBM_MODE_3WAY) return sg_fail(ADF_EBADARG, "only StereoSGBM::MODE_SGBM_3WAY (the sample's mode) is implemented on the device");
+    if (h->num_disp <= 0 || h->num_disp % 16) return sg_fail(ADF_EBADARG, "numDisparities must be positive and divisible by 16");
+    if (h->num_disp > 512) return sg_fail(ADF_EBADARG, "numDisparities above 512 is not supported");
+    const int bs = h->block > 0 ? h->block : 5;
+    if (bs % 2 == 0 || bs > 11) return sg_fail(ADF_EBADARG, "blockSize must be odd and at most 11");
+    if (h->min_disp < -2047 || h->min_disp + h->num_disp > 2047) return sg_fail(ADF_EBADARG, "disparity range does not fit CV_16S with 4 fractional bits");
+    if (h->P1 < 0 || h->P2 < 0 || h->P1 > 8000 || h->P2 > 16000) return sg_fail(ADF_EBADARG, "P1 / P2 out of range");
+    return ADF_OK;
+}
+
+extern "C" int adf_sgbm_compute_device(adf_sgbm_t* h, int n_pairs,
+                                       const uint8_t* left, ptrdiff_t left_stride, ptrdiff_t left_pair_stride,
+                                       const uint8_t* right, ptrdiff_t right_stride, ptrdiff_t right_pair_stride,
+                                       int channels, int W, int H,
+                                       int16_t* disparity, ptrdiff_t disp_stride, ptrdiff_t disp_pair_stride,
+                                       void* stream)
+{
+    int rc = sgbm_check(h, n_pairs, left, right, disparity, channels, W, H, left_stride, right_stride, disp_stride);
+    if (rc) return rc;
+    if (n_pairs > 1 && (disp_pair_stride & 1)) return sg_fail(ADF_ESIZE, "disparity maps must be 2-byte aligned");
+    hipStream_t st = (hipStream_t)stream;
+    DevScope ds(h->device);
+    const int cn = channels, D = h->num_disp, minD = h->min_disp, maxD = minD + D;
+    const int bs = h->block > 0 ? h->block : 5;
+    const int P1 = h->P1 > 0 ? h->P1 : 2, P2 = std::max(h->P2 > 0 ? h->P2 : 5, P1 + 1);
+    const int ur = h->uniq >= 0 ? h->uniq : 10;
+    const int ftzero = std::max(h->cap, 15) | 1;
+    const int minX1 = std::max(maxD, 0), w1 = (W + std::min(minD, 0)) - minX1;
+    const int16_t invalid = (int16_t)((minD - 1) * SG_DISP_SCALE);
+
+    // workspace per image in flight: two signal planes, the C and S volumes, the raw map (every part 256-byte aligned)
+    auto up256 = [](size_t b) { return (b + 255) / 256 * 256; };
+    const size_t rec_bytes = up256((size_t)W * H * cn * 3 * 4);
+    const size_t rec_pair = rec_bytes / 4;                                            // dwords
+    const size_t vol_bytes = up256(w1 > 0 ? (size_t)H * w1 * D * 2 : 0);
+    const size_t volp = vol_bytes / 2;                                                // int16 elements
+    const size_t raw_bytes = up256((size_t)W * H * 2);
+    const size_t raw_el = raw_bytes / 2;
+    const size_t per_img = 2 * rec_bytes + 2 * vol_bytes + raw_bytes;
+    int chunk = (int)(h->ws_limit / per_img);
+    if (chunk < 1) chunk = 1;
+    if (chunk > n_pairs) chunk = n_pairs;
+    rc = sg_reserve(&h->ws, &h->ws_bytes, per_img * (size_t)chunk, st);
+    if (rc) return rc;
+    char* wsb = (char*)h->ws;
+    uint32_t* rec1 = (uint32_t*)wsb;
+    uint32_t* rec2 = (uint32_t*)(wsb + rec_bytes * chunk);
+    int16_t* Cv = (int16_t*)(wsb + 2 * rec_bytes * chunk);
+    int16_t* Sv = (int16_t*)(wsb + 2 * rec_bytes * chunk + vol_bytes * chunk);
+    int16_t* raw = (int16_t*)(wsb + 2 * rec_bytes * chunk + 2 * vol_bytes * chunk);
+
+    for (int first = 0; first < n_pairs; first += chunk) {
+        const int n = std::min(chunk, n_pairs - first);
+        const uint8_t* L = left + (ptrdiff_t)first * left_pair_stride;
+        const uint8_t* R = right + (ptrdiff_t)first * right_pair_stride;
+        int16_t* out = (int16_t*)((char*)disparity + (ptrdiff_t)first * disp_pair_stride);
+        FillArgs fa{raw, W, (ptrdiff_t)raw_el, W, H, invalid};
+        hipLaunchKernelGGL(sgbm_fill_kernel, dim3((W + 255) / 256, H, n), dim3(256), 0, st, fa);
+        if (w1 > 0) {
+            SignalArgs sa{L, left_stride, left_pair_stride, cn, W, H, ftzero, rec1, rec_pair};
+            hipLaunchKernelGGL(sgbm_signals_kernel, dim3((W + 255) / 256, H, n), dim3(256), 0, st, sa);
+            sa.img = R; sa.stride = right_stride; sa.pair_stride = right_pair_stride; sa.rec = rec2;
+            hipLaunchKernelGGL(sgbm_signals_kernel, dim3((W + 255) / 256, H, n), dim3(256), 0, st, sa);
+            CostArgs ca{rec1, rec2, rec_pair, Cv, volp, W, H, D, minD, minX1, w1, 0};
+            // bands: the bs-1 warm-up rows are paid per band; enough workgroups to fill the chip when the image is small
+            int rpb = 128;
+            while (rpb > 16 && (size_t)((H + rpb - 1) / rpb) * w1 * n < 4096) rpb >>= 1;
+            ca.rows_per_band = rpb;
+            const dim3 cgrid(w1, (H + rpb - 1) / rpb, n), cblock((D + 63) / 64 * 64);
+            hipError_t e = cn == 1 ? launch_cost<1>(ca, bs, cgrid, cblock, st) : launch_cost<3>(ca, bs, cgrid, cblock, st);
+            if (e != hipSuccess) return sg_fail(ADF_EHIP, hipGetErrorString(e));
+            PathArgs pa{Cv, Sv, volp, W, H, D, minD, minX1, w1, P1, P2, ur, raw, (ptrdiff_t)W, (ptrdiff_t)raw_el};
+            e = D <= 64 ? launch_paths<1>(pa, n, st) : D <= 128 ? launch_paths<2>(pa, n, st)
+              : D <= 256 ? launch_paths<4>(pa, n, st) : launch_paths<8>(pa, n, st);
+            if (e != hipSuccess) return sg_fail(ADF_EHIP, hipGetErrorString(e));
+        }
+        MedianArgs ma{raw, (ptrdiff_t)W, (ptrdiff_t)raw_el, out, disp_stride / 2, disp_pair_stride / 2, W, H};
+        hipLaunchKernelGGL(sgbm_median_kernel, dim3((W + 255) / 256, H, n), dim3(256), 0, st, ma);
+    }
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return sg_fail(ADF_EHIP, hipGetErrorString(e));
+    return ADF_OK;
+}
+
+extern "C" int adf_sgbm_compute_host(adf_sgbm_t* h, int n_pairs,
+                                     const uint8_t* left, ptrdiff_t left_stride, ptrdiff_t left_pair_stride,
+                                     const uint8_t* right, ptrdiff_t right_stride, ptrdiff_t right_pair_stride,
+                                     int channels, int W, int H,
+                                     int16_t* disparity, ptrdiff_t disp_stride, ptrdiff_t disp_pair_stride)
+{
+    int rc = sgbm_check(h, n_pairs, left, right, disparity, channels, W, H, left_stride, right_stride, disp_stride);
+    if (rc) return rc;
+    DevScope ds(h->device);
+    const size_t vrow = (size_t)W * channels, vbytes = vrow * H, dbytes = (size_t)W * H * 2;
+    rc = sg_reserve(&h->stage, &h->stage_bytes, (2 * vbytes + dbytes) * (size_t)n_pairs + 512, nullptr);
+    if (rc) return rc;
+    uint8_t* dl = (uint8_t*)h->stage;
+    uint8_t* dr = dl + vbytes * n_pairs;
+    int16_t* dd = (int16_t*)(((uintptr_t)(dr + vbytes * n_pairs) + 255) & ~(uintptr_t)255);
+    for (int i = 0; i < n_pairs; i++) {
+        if (hipMemcpy2D(dl + vbytes * i, vrow, left + (ptrdiff_t)i * left_pair_stride, left_stride, vrow, H, hipMemcpyHostToDevice) != hipSuccess ||
+            hipMemcpy2D(dr + vbytes * i, vrow, right + (ptrdiff_t)i * right_pair_stride, right_stride, vrow, H, hipMemcpyHostToDevice) != hipSuccess)
+            return sg_fail(ADF_EHIP, "copying the views to the device failed");
+    }
+    rc = adf_sgbm_compute_device(h, n_pairs, dl, (ptrdiff_t)vrow, (ptrdiff_t)vbytes, dr, (ptrdiff_t)vrow, (ptrdiff_t)vbytes, channels, W, H,
+                                 dd, (ptrdiff_t)W * 2, (ptrdiff_t)dbytes, nullptr);
+    if (rc) return rc;
+    for (int i = 0; i < n_pairs; i++)
+        if (hipMemcpy2D((char*)disparity + (ptrdiff_t)i * disp_pair_stride, disp_stride, (char*)dd + dbytes * i, (size_t)W * 2,
+                        (size_t)W * 2, H, hipMemcpyDeviceToHost) != hipSuccess)
+            return sg_fail(ADF_EHIP, "copying the disparity map back failed");
+    return ADF_OK;
+}

@@ -283,7 +283,8 @@ class DisparityWLSFilter(DisparityFilter):
 # Matchers.  cv::StereoBM / cv::StereoSGBM live in OpenCV's calib3d, which is outside the reference tree;
 # the factories below only need the parameter accessors.  StereoBM additionally carries compute(), the
 # published block-matching algorithm on the device (csrc/bm_matcher.hip; parity unpinned
-# at the calib3d boundary, bit-exact against oracle/adf_oracle_bm.c); StereoSGBM is a parameter holder only.
+# at the calib3d boundary, bit-exact against oracle/adf_oracle_bm.c); StereoSGBM.compute() is the semi-global matcher in
+# the sample's mode (csrc/sgbm_matcher.hip, bit-exact against oracle/adf_oracle_sgbm.c).
 # ---------------------------------------------------------------------------------------------
 class StereoMatcher:
     def __init__(self, minDisparity=0, numDisparities=16, blockSize=3):
@@ -415,13 +416,31 @@ class StereoBM(StereoMatcher):
 
 
 class StereoSGBM(StereoMatcher):
+    """cv::StereoSGBM's accessors plus compute() on the device (csrc/sgbm_matcher.hip): the published semi-global
+    algorithm with three paths (MODE_SGBM_3WAY, the mode the reference's sample selects:
+    samples/disparity_filtering.cpp:166-176), bit-exact against oracle/adf_oracle_sgbm.c; parity unpinned at calib3d."""
+    MODE_SGBM, MODE_HH, MODE_SGBM_3WAY = 0, 1, 2
+
     def __init__(self, minDisparity=0, numDisparities=16, blockSize=3, P1=0, P2=0, mode=0, preFilterCap=0):
         super().__init__(minDisparity, numDisparities, blockSize)
         self.P1, self.P2, self.mode, self.preFilterCap = P1, P2, mode, preFilterCap
+        self.disp12MaxDiff = 0          # cv::StereoSGBM::create's default (the filter factory raises it to 1000000)
+        self._h = None
 
     @staticmethod
-    def create(minDisparity=0, numDisparities=16, blockSize=3):
-        return StereoSGBM(minDisparity, numDisparities, blockSize)
+    def create(minDisparity=0, numDisparities=16, blockSize=3, P1=0, P2=0, disp12MaxDiff=0, preFilterCap=0,
+               uniquenessRatio=0, speckleWindowSize=0, speckleRange=0, mode=0):
+        m = StereoSGBM(minDisparity, numDisparities, blockSize, P1, P2, mode, preFilterCap)
+        m.disp12MaxDiff, m.uniquenessRatio, m.speckleWindowSize = disp12MaxDiff, uniquenessRatio, speckleWindowSize
+        return m
+
+    def __del__(self):
+        h, self._h = getattr(self, "_h", None), None
+        if h:
+            try:
+                _lib.lib().adf_sgbm_destroy(h)
+            except Exception:
+                pass
 
     def getP1(self): return self.P1
     def setP1(self, v): self.P1 = v
@@ -433,8 +452,47 @@ class StereoSGBM(StereoMatcher):
     def setPreFilterCap(self, v): self.preFilterCap = v
 
     def compute(self, left, right, disparity=None):
-        """Not built: the semi-global matcher is a parameter holder for the factories only."""
-        raise AdfError(_lib.ADF_EBADARG, "StereoSGBM.compute is not implemented on the device; StereoBM.compute is")
+        """StereoMatcher::compute: CV_8UC1 / CV_8UC3 views (H,W[,3]) or a batch (N,H,W[,3]) -> CV_16SC1 disparity*16,
+        invalid pixels (minDisparity-1)*16.  torch CUDA tensors are matched where they are, asynchronously on torch's
+        current stream; numpy arrays take the host entry point.  Only MODE_SGBM_3WAY is built; the matcher's own
+        left-right check and speckle filter are not (the filter factory switches both off, DF.cpp:389-390)."""
+        if self.mode != StereoSGBM.MODE_SGBM_3WAY:
+            raise AdfError(_lib.ADF_EBADARG, "only StereoSGBM.MODE_SGBM_3WAY (the sample's mode) is implemented on the device")
+        if self.disp12MaxDiff < 1000000:
+            raise AdfError(_lib.ADF_EBADARG, "disp12MaxDiff (left-right check inside the matcher) is not implemented: "
+                                             "createDisparityWLSFilter sets it to 1000000")
+        if self.speckleWindowSize > 0:
+            raise AdfError(_lib.ADF_EBADARG, "speckle filtering is not implemented")
+        nd = len(left.shape)
+        color = nd in (3, 4) and left.shape[-1] == 3      # (H,W,3) / (N,H,W,3); a batch of 3-pixel-wide gray images is not a case
+        batched = nd == (4 if color else 3)
+        L = _Image(left, np.uint8, "left", batched, allow_channels=(1, 3))
+        R = _Image(right, np.uint8, "right", batched, allow_channels=(1, 3))
+        if (L.n, L.h, L.w, L.c) != (R.n, R.h, R.w, R.c):
+            raise AdfError(_lib.ADF_ESIZE, "All the images must have the same size")
+        if L.device != R.device:
+            raise AdfError(_lib.ADF_EBADARG, "left and right must live on the same side (host or device)")
+        if disparity is None:
+            disparity = _out_like(L, batched, np.int16)
+        D = _Image(disparity, np.int16, "disparity", batched)
+        if (D.n, D.h, D.w) != (L.n, L.h, L.w) or D.device != L.device:
+            raise AdfError(_lib.ADF_ESIZE, "disparity must match the views")
+        lib = _lib.lib()
+        if self._h is None:
+            h = C.c_void_p()
+            _lib.check(lib.adf_sgbm_create(C.byref(h), int(self.minDisparity), int(self.numDisparities), int(self.blockSize)))
+            self._h = h
+        _check_device(lib.adf_sgbm_get_device, self._h, [L, R, D], "this StereoSGBM")
+        _lib.check(lib.adf_sgbm_set_params(self._h, int(self.minDisparity), int(self.numDisparities), int(self.blockSize),
+                                           int(self.P1), int(self.P2), int(self.preFilterCap), int(self.uniquenessRatio),
+                                           int(self.mode)))
+        args = [self._h, L.n, C.c_void_p(L.ptr), L.stride, L.pair_stride, C.c_void_p(R.ptr), R.stride, R.pair_stride,
+                L.c, L.w, L.h, C.c_void_p(D.ptr), D.stride, D.pair_stride]
+        if L.device:
+            _lib.check(lib.adf_sgbm_compute_device(*args, _stream_of(L)))
+        else:
+            _lib.check(lib.adf_sgbm_compute_host(*args))
+        return disparity
 
 
 def createDisparityWLSFilter(matcher_left):

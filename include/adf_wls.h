@@ -286,6 +286,44 @@ int adf_bm_compute_host(adf_bm_t* h, int n_pairs,
                         int W, int H,
                         int16_t* disparity, ptrdiff_t disp_stride, ptrdiff_t disp_pair_stride);
 
+/* ---------------- semi-global matcher feeding the filter ----------------
+ * cv::StereoSGBM as the reference's sample configures it (samples/disparity_filtering.cpp:166-176, 229-235:
+ * P1 = 24*w*w, P2 = 96*w*w, preFilterCap 63, MODE_SGBM_3WAY) and as its factories expect it
+ * (disparity_filters.cpp:404-409, 432-445): the published semi-global algorithm (Hirschmueller 2008) with the
+ * Birchfield-Tomasi block cost and three paths (left, top, right), sub-pixel fit, 3x3 median of the result;
+ * CV_16SC1 with 4 fractional bits, invalid pixels (minDisparity-1)*16, matchable columns
+ * [max(minDisparity+numDisparities,0), W+min(minDisparity,0)).  The class itself lives in OpenCV's calib3d (outside
+ * the reference tree: parity unpinned); results are bit-exact against oracle/adf_oracle_sgbm.c and anchored on the
+ * reference's own semi-global test (modules/stereo/test/test_block_matching.cpp:157-238).  Not implemented, and not
+ * reachable from the filter (its factories switch them off): the matcher's own left-right check (disp12MaxDiff) and
+ * speckle filter; MODE_SGBM / MODE_HH.  Limits: numDisparities <= 512, blockSize odd <= 11. */
+#define ADF_SGBM_MODE_SGBM 0
+#define ADF_SGBM_MODE_HH 1
+#define ADF_SGBM_MODE_3WAY 2 /* StereoSGBM::MODE_SGBM_3WAY */
+typedef struct adf_sgbm adf_sgbm_t; /* cv::Ptr<StereoSGBM> */
+/* StereoSGBM::create(minDisparity, numDisparities, blockSize); the other parameters start at its defaults
+ * (P1 = P2 = 0, preFilterCap 0, uniquenessRatio 10, mode MODE_SGBM). */
+int adf_sgbm_create(adf_sgbm_t** out, int min_disparity, int num_disparities, int block_size);
+void adf_sgbm_destroy(adf_sgbm_t* h);
+int adf_sgbm_get_device(const adf_sgbm_t* h, int* device);
+int adf_sgbm_set_params(adf_sgbm_t* h, int min_disparity, int num_disparities, int block_size, int P1, int P2,
+                        int prefilter_cap, int uniqueness_ratio, int mode);
+int adf_sgbm_get_params(const adf_sgbm_t* h, int* min_disparity, int* num_disparities, int* block_size, int* P1, int* P2,
+                        int* prefilter_cap, int* uniqueness_ratio, int* mode);
+/* StereoMatcher::compute(left, right, disparity) on n_pairs equally sized CV_8UC1 / CV_8UC3 pairs (`channels`);
+ * disparity: CV_16SC1, W x H (strides in bytes).  Asynchronous on `stream`. */
+int adf_sgbm_compute_device(adf_sgbm_t* h, int n_pairs,
+                            const uint8_t* left, ptrdiff_t left_stride, ptrdiff_t left_pair_stride,
+                            const uint8_t* right, ptrdiff_t right_stride, ptrdiff_t right_pair_stride,
+                            int channels, int W, int H,
+                            int16_t* disparity, ptrdiff_t disp_stride, ptrdiff_t disp_pair_stride,
+                            void* stream);
+int adf_sgbm_compute_host(adf_sgbm_t* h, int n_pairs,
+                          const uint8_t* left, ptrdiff_t left_stride, ptrdiff_t left_pair_stride,
+                          const uint8_t* right, ptrdiff_t right_stride, ptrdiff_t right_pair_stride,
+                          int channels, int W, int H,
+                          int16_t* disparity, ptrdiff_t disp_stride, ptrdiff_t disp_pair_stride);
+
 #ifdef __cplusplus
 }
 #endif

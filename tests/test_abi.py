@@ -77,8 +77,12 @@ def test_matcher_factories_host_logic():
         adf.createRightMatcher(adf.StereoMatcher())
     with pytest.raises(adf.AdfError):
         adf.createDisparityWLSFilter(adf.StereoMatcher())
-    with pytest.raises(adf.AdfError):                       # the semi-global matcher is a parameter holder only
+    with pytest.raises(adf.AdfError):                       # only the sample's mode (MODE_SGBM_3WAY) is built on the device
         right.compute(np.zeros((8, 8), np.uint8), np.zeros((8, 8), np.uint8))
+    fresh = adf.StereoSGBM.create(0, 16, 3)
+    fresh.setMode(adf.StereoSGBM.MODE_SGBM_3WAY)
+    with pytest.raises(adf.AdfError):                       # ... and not the matcher's own left-right check (create's default)
+        fresh.compute(np.zeros((8, 8), np.uint8), np.zeros((8, 8), np.uint8))
 
 
 def test_synthetic_example_shape_and_determinism():
