@@ -179,20 +179,15 @@ __device__ __forceinline__ int wave_min_i32(int v)
 template <int DPL> struct Vec16 { int16_t v[DPL]; };
 
 template <int DPL>
-__device__ __forceinline__ void load_costs(const int16_t* p, bool active, int (&o)[DPL])
+__device__ __forceinline__ void load_costs(const int16_t* p, int (&o)[DPL])
 {
-    // a lane's DPL disparities are all inside [0, D) or all outside (D is a multiple of 16, DPL divides 16)
+    // unconditional (lanes without disparities read lane 0's and ignore them): no load under a branch
     typedef short vs __attribute__((ext_vector_type(DPL)));
-    if (active) {
-        if constexpr (DPL == 1) o[0] = p[0];
-        else {
-            const vs q = *reinterpret_cast<const vs*>(p);
+    if constexpr (DPL == 1) o[0] = p[0];
+    else {
+        const vs q = *reinterpret_cast<const vs*>(p);
 #pragma unroll
-            for (int k = 0; k < DPL; k++) o[k] = q[k];
-        }
-    } else {
-#pragma unroll
-        for (int k = 0; k < DPL; k++) o[k] = 0;
+        for (int k = 0; k < DPL; k++) o[k] = q[k];
     }
 }
 
@@ -214,6 +209,7 @@ template <int DPL, int DIR>
 __global__ void __launch_bounds__(256) sgbm_path_kernel(PathArgs a)
 {
     __shared__ int16_t sS[4][64 * DPL];                       // DIR_RIGHT: the pixel's S(d) for the sub-pixel fit
+    extern __shared__ int16_t sOut[];                         // DIR_RIGHT: [4][w1] the scanline's results (written out coalesced)
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int line = blockIdx.x * 4 + wv;                     // scanline: column (TOP) or row (LEFT / RIGHT)
     const int nlines = DIR == DIR_TOP ? a.w1 : a.H;
@@ -222,8 +218,9 @@ __global__ void __launch_bounds__(256) sgbm_path_kernel(PathArgs a)
     const int d0 = lane * DPL;
     const bool active = d0 < a.D;
     const size_t vol0 = (size_t)blockIdx.y * a.vol;
-    const int16_t* C = a.C + vol0 + d0;
-    int16_t* S = a.S + vol0 + d0;
+    // a lane's DPL disparities are all inside [0, D) or all outside (D is a multiple of 16, DPL divides 16)
+    const int16_t* C = a.C + vol0 + (active ? d0 : 0);
+    int16_t* S = a.S + vol0 + (active ? d0 : 0);
     // element offset of step t
     auto offs = [&](int t) -> size_t {
         if (DIR == DIR_TOP) return ((size_t)t * a.w1 + line) * a.D;
@@ -234,20 +231,13 @@ __global__ void __launch_bounds__(256) sgbm_path_kernel(PathArgs a)
 #pragma unroll
     for (int k = 0; k < DPL; k++) L[k] = active ? 0 : SG_MAX_COST;      // zero start (stereo_binary_sgbm.cpp:191-194)
     int minprev = 0;
-    int cnext[DPL], snext[DPL];
-    load_costs<DPL>(C + offs(0), active, cnext);
-    if (DIR != DIR_TOP) load_costs<DPL>(S + offs(0), active, snext);
-    int16_t* out = DIR == DIR_RIGHT ? a.out + (ptrdiff_t)blockIdx.y * a.out_pair + (ptrdiff_t)line * a.out_stride : nullptr;
-    for (int t = 0; t < nsteps; t++) {
-        int c[DPL], s[DPL];
-#pragma unroll
-        for (int k = 0; k < DPL; k++) { c[k] = cnext[k]; s[k] = DIR != DIR_TOP ? snext[k] : 0; }
+    const int16_t invalid = (int16_t)((a.minD - 1) * SG_DISP_SCALE);
+    int16_t* myOut = sOut + wv * a.w1;
+
+    // one step of formula 13 at scanline position t with the operands c (block cost) and s (S so far)
+    auto step = [&](int t, const int (&c)[DPL], const int (&s)[DPL]) {
         const size_t o = offs(t);
-        if (t + 1 < nsteps) {                                  // next step's operands are in flight during this one
-            load_costs<DPL>(C + offs(t + 1), active, cnext);
-            if (DIR != DIR_TOP) load_costs<DPL>(S + offs(t + 1), active, snext);
-        }
-        // formula 13 (stereo_binary_sgbm.cpp:419-446): neighbours d-1 / d+1, guards SHRT_MAX outside [0, D)
+        // stereo_binary_sgbm.cpp:419-446: neighbours d-1 / d+1, guards SHRT_MAX outside [0, D)
         const int lm = __builtin_amdgcn_update_dpp(SG_MAX_COST, L[DPL - 1], 0x138, 0xf, 0xf, false);   // wave_shr:1
         const int lp = __builtin_amdgcn_update_dpp(SG_MAX_COST, L[0], 0x130, 0xf, 0xf, false);         // wave_shl:1
         const int delta = minprev + a.P2;
@@ -285,18 +275,60 @@ __global__ void __launch_bounds__(256) sgbm_path_kernel(PathArgs a)
                 }
                 const bool any_reject = __builtin_amdgcn_ballot_w64(reject) != 0;
                 store_costs<DPL>(&sS[wv][d0], active, st);
-                if (minS < SG_MAX_COST && !any_reject && lane == 0) {
-                    int d = best;
+                // (results go to LDS only: no vector-memory operation under a branch inside the pipelined loop)
+                int res = invalid;
+                if (minS < SG_MAX_COST && !any_reject) {
+                    int d = best < a.D ? best : 0;
+                    const int dm = d > 0 ? d - 1 : 0, dp = d < a.D - 1 ? d + 1 : d;
+                    const int sm = sS[wv][dm], s0 = sS[wv][d], sp = sS[wv][dp];
                     if (0 < d && d < a.D - 1) {                // stereo_binary_sgbm.cpp:584-591
-                        const int sm = sS[wv][d - 1], s0 = sS[wv][d], sp = sS[wv][d + 1];
                         const int denom2 = max(sm + sp - 2 * s0, 1);
                         d = d * SG_DISP_SCALE + ((sm - sp) * SG_DISP_SCALE + denom2) / (denom2 * 2);
                     } else
                         d *= SG_DISP_SCALE;
-                    out[a.minX1 + (a.w1 - 1 - t)] = (int16_t)(d + a.minD * SG_DISP_SCALE);   // :596
+                    res = d + a.minD * SG_DISP_SCALE;           // :596
                 }
+                if (lane == 0) myOut[a.w1 - 1 - t] = (int16_t)res;
             }
         }
+    };
+
+    // Operands of the next PF steps are in flight while a step is reduced (a step is far shorter than a memory
+    // latency).  The pipelined loop has NO branch around a vector-memory operation: with one, the compiler can only
+    // wait for every outstanding load at each use, which serialises the ring.
+    constexpr int PF = DPL >= 8 ? 4 : 8;
+    int cq[PF][DPL], sq[PF][DPL];
+#pragma unroll
+    for (int p = 0; p < PF; p++) {
+        const int tt = p < nsteps ? p : nsteps - 1;
+        load_costs<DPL>(C + offs(tt), cq[p]);
+        if (DIR != DIR_TOP) load_costs<DPL>(S + offs(tt), sq[p]);
+        else {
+#pragma unroll
+            for (int k = 0; k < DPL; k++) sq[p][k] = 0;
+        }
+    }
+    int t0 = 0;
+    for (; t0 + PF <= nsteps; t0 += PF) {
+#pragma unroll
+        for (int p = 0; p < PF; p++) {
+            const int t = t0 + p;
+            int c[DPL], s[DPL];
+#pragma unroll
+            for (int k = 0; k < DPL; k++) { c[k] = cq[p][k]; s[k] = sq[p][k]; }
+            const int tt = t + PF < nsteps ? t + PF : nsteps - 1;
+            load_costs<DPL>(C + offs(tt), cq[p]);
+            if (DIR != DIR_TOP) load_costs<DPL>(S + offs(tt), sq[p]);
+            step(t, c, s);
+        }
+    }
+#pragma unroll
+    for (int p = 0; p < PF; p++)                              // the last nsteps % PF steps: operands already in the ring
+        if (t0 + p < nsteps) step(t0 + p, cq[p], sq[p]);
+
+    if (DIR == DIR_RIGHT) {                                   // the scanline's results, coalesced
+        int16_t* out = a.out + (ptrdiff_t)blockIdx.y * a.out_pair + (ptrdiff_t)line * a.out_stride + a.minX1;
+        for (int x = lane; x < a.w1; x += 64) out[x] = myOut[x];
     }
 }
 
@@ -367,7 +399,13 @@ hipError_t launch_paths(const PathArgs& a, int n, hipStream_t st)
 {
     hipLaunchKernelGGL((sgbm_path_kernel<DPL, DIR_TOP>), dim3((a.w1 + 3) / 4, n), dim3(256), 0, st, a);
     hipLaunchKernelGGL((sgbm_path_kernel<DPL, DIR_LEFT>), dim3((a.H + 3) / 4, n), dim3(256), 0, st, a);
-    hipLaunchKernelGGL((sgbm_path_kernel<DPL, DIR_RIGHT>), dim3((a.H + 3) / 4, n), dim3(256), 0, st, a);
+    const size_t lds_out = (size_t)a.w1 * 4 * sizeof(int16_t);
+    if (lds_out > 48 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(sgbm_path_kernel<DPL, DIR_RIGHT>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_out);
+        if (e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL((sgbm_path_kernel<DPL, DIR_RIGHT>), dim3((a.H + 3) / 4, n), dim3(256), lds_out, st, a);
     return hipGetLastError();
 }
 
