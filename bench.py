@@ -318,6 +318,11 @@ def worker(args):
     # ---- correctness of what is being timed: first and last pair of EVERY rank against the CPU oracle ----
     checked = None
     if not args.no_check and not dry:
+        import oracle
+        if rank == 0:
+            oracle.build()            # one rank compiles the checker if its .so is stale; the others wait
+        if world > 1:
+            dist.barrier()
         if args.warmup <= 0:
             step(); sync()
         cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else 8

@@ -312,6 +312,81 @@ inline Ptr<StereoBM> createRightMatcher(const Ptr<StereoBM>& matcher_left)
     return right_bm;
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// Semi-global matcher feeding the filter: cv::StereoSGBM's accessor names over adf_sgbm_*, the
+// sample's other producer (samples/disparity_filtering.cpp:166-176).  Only MODE_SGBM_3WAY is built on the device.
+// ---------------------------------------------------------------------------------------------------------
+class StereoSGBM {
+    adf_sgbm_t* h_ = nullptr;
+    int min_disp_, num_disp_, block_, P1_ = 0, P2_ = 0, cap_ = 0, uniq_ = 10, mode_ = MODE_SGBM;   // cv::StereoSGBM::create's defaults
+    int disp12_ = 0, speckle_window_ = 0;
+public:
+    enum { MODE_SGBM = ADF_SGBM_MODE_SGBM, MODE_HH = ADF_SGBM_MODE_HH, MODE_SGBM_3WAY = ADF_SGBM_MODE_3WAY };
+    StereoSGBM(int minDisparity, int numDisparities, int blockSize) : min_disp_(minDisparity), num_disp_(numDisparities), block_(blockSize)
+    {
+        check(adf_sgbm_create(&h_, min_disp_, num_disp_, block_));
+    }
+    ~StereoSGBM() { adf_sgbm_destroy(h_); }
+    StereoSGBM(const StereoSGBM&) = delete;
+    StereoSGBM& operator=(const StereoSGBM&) = delete;
+    static Ptr<StereoSGBM> create(int minDisparity = 0, int numDisparities = 16, int blockSize = 3)
+    {
+        return Ptr<StereoSGBM>(new StereoSGBM(minDisparity, numDisparities, blockSize));
+    }
+    int getMinDisparity() const { return min_disp_; }        void setMinDisparity(int v) { min_disp_ = v; }
+    int getNumDisparities() const { return num_disp_; }      void setNumDisparities(int v) { num_disp_ = v; }
+    int getBlockSize() const { return block_; }              void setBlockSize(int v) { block_ = v; }
+    int getP1() const { return P1_; }                        void setP1(int v) { P1_ = v; }
+    int getP2() const { return P2_; }                        void setP2(int v) { P2_ = v; }
+    int getPreFilterCap() const { return cap_; }             void setPreFilterCap(int v) { cap_ = v; }
+    int getUniquenessRatio() const { return uniq_; }         void setUniquenessRatio(int v) { uniq_ = v; }
+    int getMode() const { return mode_; }                    void setMode(int v) { mode_ = v; }
+    int getDisp12MaxDiff() const { return disp12_; }         void setDisp12MaxDiff(int v) { disp12_ = v; }
+    int getSpeckleWindowSize() const { return speckle_window_; } void setSpeckleWindowSize(int v) { speckle_window_ = v; }
+    // StereoMatcher::compute: CV_8UC1 / CV_8UC3 views -> CV_16SC1 disparity * 16, invalid pixels (minDisparity - 1) * 16
+    void compute(const Mat& left, const Mat& right, Mat& disparity)
+    {
+        if (left.empty() || right.empty() || mat_depth(left) != D8U || mat_depth(right) != D8U ||
+            (mat_channels(left) != 1 && mat_channels(left) != 3) || mat_channels(left) != mat_channels(right))
+            throw Exception(ADF_EBADARG, "Both input images must have CV_8UC1 or CV_8UC3");
+        if (left.rows != right.rows || left.cols != right.cols)
+            throw Exception(ADF_ESIZE, "All the images must have the same size");
+        if (disp12_ < 1000000 || speckle_window_ > 0)                            // the filter factory switches both off (DF.cpp:389-390)
+            throw Exception(ADF_EBADARG, "the matcher's own left-right check and speckle filter are not implemented");
+        check(adf_sgbm_set_params(h_, min_disp_, num_disp_, block_, P1_, P2_, cap_, uniq_, mode_));
+        Mat out;
+        mat_create(out, left.rows, left.cols, D16S, 1);
+        check(adf_sgbm_compute_host(h_, 1, left.data, mat_step(left), 0, right.data, mat_step(right), 0, mat_channels(left),
+                                    left.cols, left.rows, reinterpret_cast<int16_t*>(out.data), mat_step(out), 0));
+        disparity = out;
+    }
+};
+
+// DF.cpp:386-391, 404-409 (StereoSGBM branch)
+inline Ptr<DisparityWLSFilter> createDisparityWLSFilter(const Ptr<StereoSGBM>& matcher_left)
+{
+    matcher_left->setDisp12MaxDiff(1000000);
+    matcher_left->setSpeckleWindowSize(0);
+    matcher_left->setUniquenessRatio(0);
+    return createDisparityWLSFilter(true, matcher_left->getMinDisparity(), matcher_left->getNumDisparities(),
+                                    matcher_left->getBlockSize());
+}
+
+// DF.cpp:432-445
+inline Ptr<StereoSGBM> createRightMatcher(const Ptr<StereoSGBM>& matcher_left)
+{
+    const int min_disp = matcher_left->getMinDisparity(), num_disp = matcher_left->getNumDisparities();
+    Ptr<StereoSGBM> right_sgbm = StereoSGBM::create(-(min_disp + num_disp) + 1, num_disp, matcher_left->getBlockSize());
+    right_sgbm->setUniquenessRatio(0);
+    right_sgbm->setP1(matcher_left->getP1());
+    right_sgbm->setP2(matcher_left->getP2());
+    right_sgbm->setMode(matcher_left->getMode());
+    right_sgbm->setPreFilterCap(matcher_left->getPreFilterCap());
+    right_sgbm->setDisp12MaxDiff(1000000);
+    right_sgbm->setSpeckleWindowSize(0);
+    return right_sgbm;
+}
+
 // EF.hpp:361-371
 class FastGlobalSmootherFilter {
     adf_fgs_t* h_ = nullptr;

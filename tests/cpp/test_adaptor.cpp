@@ -132,6 +132,37 @@ int main()
         bool threw = false;
         try { StereoBM::create(24, 9)->compute(left, right, dl); } catch (const Exception&) { threw = true; }   // not divisible by 16
         EXPECT(threw);
+
+        // the sample's other producer (disparity_filtering.cpp:166-176): StereoSGBM in MODE_SGBM_3WAY, both views, filter
+        const int bs = 3;
+        Ptr<StereoSGBM> sl = StereoSGBM::create(0, nd, bs);
+        sl->setP1(24 * bs * bs); sl->setP2(96 * bs * bs); sl->setPreFilterCap(63); sl->setMode(StereoSGBM::MODE_SGBM_3WAY);
+        Ptr<DisparityWLSFilter> wls2 = createDisparityWLSFilter(sl);           // DF.cpp:404-409
+        Ptr<StereoSGBM> sr = createRightMatcher(sl);                           // DF.cpp:432-445
+        EXPECT(sl->getDisp12MaxDiff() == 1000000 && sl->getUniquenessRatio() == 0 && sr->getMinDisparity() == -nd + 1 &&
+               sr->getP1() == 24 * bs * bs && sr->getMode() == StereoSGBM::MODE_SGBM_3WAY && wls2->getDepthDiscontinuityRadius() == 2);
+        wls2->setLambda(8000.0); wls2->setSigmaColor(1.5); wls2->setSolver(ADF_SOLVER_EXACT);
+        Mat sdl, sdr, sout;
+        sl->compute(left, right, sdl);
+        sr->compute(right, left, sdr);
+        wls2->filter(sdl, left, sout, sdr);
+        adf_oracle_sgbm_params sp = {0, nd, bs, 24 * bs * bs, 96 * bs * bs, 63, 0, ADF_SGBM_MODE_3WAY};
+        EXPECT(adf_oracle_sgbm_compute(&sp, left.data, (ptrdiff_t)left.step, right.data, (ptrdiff_t)right.step, 1, W, H, edl.ptr<int16_t>(), W, nullptr) == 0);
+        sp.min_disparity = -nd + 1;
+        EXPECT(adf_oracle_sgbm_compute(&sp, right.data, (ptrdiff_t)right.step, left.data, (ptrdiff_t)left.step, 1, W, H, edr.ptr<int16_t>(), W, nullptr) == 0);
+        EXPECT(std::memcmp(sdl.data, edl.data, (size_t)H * edl.step) == 0);
+        EXPECT(std::memcmp(sdr.data, edr.data, (size_t)H * edr.step) == 0);
+        Rect r2 = wls2->getROI();
+        EXPECT(r2.x == nd && r2.y == 0 && r2.width == W - nd && r2.height == H);
+        p.disc_radius = 2;
+        EXPECT(adf_oracle_wls_filter(&p, edl.ptr<int16_t>(), (ptrdiff_t)edl.step, left.data, (ptrdiff_t)left.step, 1, W, H,
+                                     edr.ptr<int16_t>(), (ptrdiff_t)edr.step, r2.x, r2.y, r2.width, r2.height,
+                                     exp.ptr<int16_t>(), (ptrdiff_t)exp.step, nullptr) == 0);
+        EXPECT(std::memcmp(sout.data, exp.data, (size_t)H * exp.step) == 0);
+        threw = false;
+        try { Ptr<StereoSGBM> q = StereoSGBM::create(0, 16, 3); q->setDisp12MaxDiff(1000000); q->compute(left, right, sdl); }
+        catch (const Exception&) { threw = true; }                             // default mode MODE_SGBM is not built on the device
+        EXPECT(threw);
     }
     {   // error behaviour: exceptions like CV_Assert / CV_Error
         Mat view(48, 64, D8U, 3), dl(48, 64, D16S, 1), out;

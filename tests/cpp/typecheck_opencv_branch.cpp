@@ -35,6 +35,13 @@ void pipeline(const cv::Mat& left, const cv::Mat& right, cv::Mat& filtered, cv::
     bm->compute(left, right, dl);
     rbm->compute(right, left, dr);
 
+    adf::Ptr<StereoSGBM> sg = StereoSGBM::create(0, 160, 3);
+    sg->setP1(24 * 9); sg->setP2(96 * 9); sg->setPreFilterCap(63); sg->setMode(StereoSGBM::MODE_SGBM_3WAY);
+    adf::Ptr<DisparityWLSFilter> wls5 = createDisparityWLSFilter(sg);
+    adf::Ptr<StereoSGBM> rsg = createRightMatcher(sg);
+    sg->compute(left, right, dl);
+    rsg->compute(right, left, dr);
+
     cv::Mat smooth;
     fastGlobalSmootherFilter(left, dl, smooth, 500.0, 1.5);
     createFastGlobalSmootherFilter(left, 500.0, 1.5, 0.25, 3)->filter(dl, smooth);
