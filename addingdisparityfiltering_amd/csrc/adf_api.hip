@@ -378,12 +378,12 @@ extern "C" int adf_wls_sync(adf_wls_t* h, void* stream)
     return ADF_OK;
 }
 
-static size_t wls_pair_ws_bytes(const Geom& g, bool conf, bool wave)
+static size_t wls_pair_ws_bytes(const Geom& g, bool conf, bool wave, bool disc_maps)
 {
     // exact: ROI planes CH CV D F0 A0 B0 (+ F1 A1 B1 with confidence); wave: CH CV A0 (+ A1), in place
-    // full frames: cL cR (confidence only)
+    // full frames: cL cR, the depth-discontinuity maps (not needed when the one-sweep confidence kernel runs)
     size_t planes = wave ? (conf ? 4 : 3) : (conf ? 9 : 6);
-    return planes * g.plane * sizeof(float) + (conf ? 2 * g.frame * sizeof(float) : 0);
+    return planes * g.plane * sizeof(float) + (conf && disc_maps ? 2 * g.frame * sizeof(float) : 0);
 }
 
 // conf_given: h->conf already holds the view-sized confidence planes of all pairs (down-scaled path,
@@ -430,7 +430,19 @@ static int wls_filter_impl(adf_wls_t* h, int n_pairs,
     // sizes outside the register-resident kernels' range fall back to the exact solver
     const bool wave = h->solver == ADF_SOLVER_WAVE && wave_fits(g);
     h->last_solver = wave ? ADF_SOLVER_WAVE : ADF_SOLVER_EXACT;
-    const size_t per_pair = wls_pair_ws_bytes(g, conf, wave);
+    // does the one-sweep confidence kernel run (both views' maps stay on chip)?  It needs the fused first row pass,
+    // whose alignment conditions depend only on the geometry, the strides and the pointers known here.
+    bool band = false;
+    if (conf && !conf_given && wave && h->conf_band && conf_band_fits(g, h->disc_radius)) {
+        WavePassArgs probe{};
+        probe.conf_in = (const float*)h->conf.p; probe.conf_frame = g.frame; probe.conf_pitch = W; probe.conf_x0 = roi.x; probe.conf_y0 = roi.y;
+        probe.dl_in = dispL; probe.dl_stride = sL; probe.dl_pair_stride = psL; probe.dl_x0 = roi.x; probe.dl_y0 = roi.y;
+        probe.len = g.rw;
+        // (h->conf.p may still be null or about to be re-allocated: hipMalloc returns 256-byte aligned memory either way)
+        if (!probe.conf_in) probe.conf_in = reinterpret_cast<const float*>(uintptr_t(256));
+        band = wave_hpass_can_fuse(probe);
+    }
+    const size_t per_pair = wls_pair_ws_bytes(g, conf, wave, !band);
     int chunk = (int)(h->ws_limit / per_pair);
     if (chunk < 1) chunk = 1;
     if (chunk > n_pairs) chunk = n_pairs;
@@ -438,7 +450,7 @@ static int wls_filter_impl(adf_wls_t* h, int n_pairs,
     if (conf && !conf_given && (rc = h->conf.reserve(g.frame * sizeof(float) * (size_t)n_pairs, st))) return rc;
 
     {
-        const long long sig[8] = {W, H, roi.x, roi.y, roi.width, roi.height, (long long)wave * 2 + conf, chunk};
+        const long long sig[8] = {W, H, roi.x, roi.y, roi.width, roi.height, (long long)band * 4 + (long long)wave * 2 + conf, chunk};
         if (memcmp(sig, h->ws_sig, sizeof(sig)) != 0) {
             HIP_TRY(hipMemsetAsync(h->ws.p, 0, h->ws.bytes, st));
             memcpy(h->ws_sig, sig, sizeof(sig));
@@ -454,7 +466,7 @@ static int wls_filter_impl(adf_wls_t* h, int n_pairs,
     if (conf) {
         p.A1 = take(g.plane);                     // wave: directly behind A0 (the pair plane spans both)
         if (!wave) { p.F1 = take(g.plane); p.B1 = take(g.plane); }
-        cL = take(g.frame); cR = take(g.frame);
+        if (!band) { cL = take(g.frame); cR = take(g.frame); }
     }
     // exact: the horizontal pass wants the row index fastest (T); wave: row-major (N), except that two
     // right-hand sides share one interleaved pair plane (A0 and A1 are adjacent: 2*plane floats per
@@ -532,7 +544,8 @@ static int wls_filter_impl(adf_wls_t* h, int n_pairs,
                 fuse.len = g.rw;
                 const bool fused_h = wave_hpass_can_fuse(fuse);
                 if (!fused_h) fuse = WavePassArgs{};
-                if (fused_h && h->conf_band && conf_band_fits(g, h->disc_radius)) {
+                if (band && !fused_h) return fail(ADF_EHIP, "internal: confidence kernel selection and first-pass fusion disagree");
+                if (band) {
                     // both views, LRC and x255 in one band sweep: the right view's map lives in LDS only
                     ConfBandArgs ba{dL, sL, psL, dRp, sR, psR, confp, g, rrx, thresh, h->disc_radius, h->roll_off, 0};
                     ProfScope ps(prof, K_LRC, 8.0 * P, 8.0 * P, st);     // dL 2 + dR 2 read, conf 4 written

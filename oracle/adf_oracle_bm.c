@@ -17,6 +17,14 @@
  *      parabola-like sub-pixel fit, result in fixed point with 4 fractional bits (CV_16SC1);
  *   4. pixels without a full search range or window column-wise, and rejected pixels, hold
  *      (minDisparity - 1) * 16.
+ * Suspected deviations from calib3d's StereoBM, recorded because nothing in the reference tree can settle them
+ * (round-1 code review, from memory of OpenCV's source): (a) calib3d may emit disparities for the outer
+ * blockSize/2 columns of [lofs, W-rofs) with clamped window columns, where this statement marks them FILTERED --
+ * createDisparityWLSFilter cuts exactly that band off the ROI (disparity_filters.cpp:401), so the filter never reads
+ * it; (b) calib3d's prefilterXSobel works on row pairs and fills the last row of an odd-height image with the cap
+ * value, where this statement filters every row with reflected neighbours -- the difference reaches block sums of
+ * the last blockSize/2 rows only, which the same ROI cut removes.  Raw matcher maps may therefore differ from
+ * OpenCV's in those bands; the filter's input inside its ROI is unaffected by (a) and by (b) up to the window reach.
  * What the reference itself fixes are the conventions around the call: the right-view matcher's
  * parameters (disparity_filters.cpp:421-431), the settings the filter forces on the matcher (:389-390,
  * 399-400: texture threshold 0, uniqueness ratio 0, no speckle filter, no left-right check) and the

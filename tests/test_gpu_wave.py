@@ -267,11 +267,11 @@ def test_device_call_is_graph_capturable(adf):
 
 
 def test_batch_beyond_4gb_workspace(adf, oracle):
-    """a batch whose workspace and planes exceed 4 GB (20 pairs of 3840x2160: 4.5 GB of planes,
-    every per-pair offset needs 64 bits) -- pairs 0, middle and last equal the single-pair call, and the last pair
-    (the one the largest offsets reach) is checked against the oracle."""
+    """a batch whose workspace and planes exceed 4 GB (32 pairs of 3840x2160: 4 GB of solver planes
+    + 1 GB of confidence maps, every per-pair offset needs 64 bits) -- pairs 0, middle and last equal the single-pair
+    call, and the last pair (the one the largest offsets reach) is checked against the oracle."""
     import torch
-    n, cfg = 20, synthetic.CONFIGS[3]
+    n, cfg = 32, synthetic.CONFIGS[3]
     W, H, roi, radius = cfg["W"], cfg["H"], cfg["roi"], cfg["radius"]
     dev = torch.device("cuda:0")
     view, dl, dr = synthetic.make_artificial_batch_torch(n, W, H, 3, 4242, cfg["rect_disparity"], dev)
