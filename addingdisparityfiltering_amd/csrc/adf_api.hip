@@ -64,7 +64,7 @@ static Geom make_geom(int W, int H, int rx, int ry, int rw, int rh)
     g.W = W; g.H = H; g.rx = rx; g.ry = ry; g.rw = rw; g.rh = rh;
     g.pw = round_up(rw, 64);
     g.ph = round_up(rh, 64);
-    size_t a = (size_t)((rh + 1) & ~1) * g.pw, b = (size_t)rw * g.ph;   // (the wave solver's pair plane holds rows in pairs)
+    size_t a = (size_t)round_up(rh, ADF_TILE_ROWS) * g.pw, b = (size_t)rw * g.ph;   // (the wave solver's pair plane holds rows in tiles)
     g.plane = ((a > b ? a : b) + 63) / 64 * 64;
     g.frame = (size_t)W * H;
     return g;
@@ -665,10 +665,18 @@ extern "C" int adf_wls_filter_scaled_device(adf_wls_t* h, int n_pairs,
         da.ry = rlo.y; da.rw = rlo.width; da.rh = rlo.height; da.radius = h->disc_radius;
         da.roll_off = h->roll_off / (resize_factor * resize_factor);        // DF.cpp:359
         da.W = dW; da.frame = lo; da.only_view = -1;
-        HIP_TRY(launch_discontinuity(da, n_pairs, st));                    // DF.cpp:204
-        LrcArgs la{dispL, sL, psL, dispR, sR, psR, cl, cr, clo, nullptr, 0, 0, 0, nullptr, nullptr, glo, rrx,
-                   (int)(resize_factor * h->lrc_thresh) /* DF.cpp:318 */, ORIENT_N};
-        HIP_TRY(launch_lrc_prologue(la, n_pairs, st));                     // DF.cpp:208-209
+        const int thresh_lo = (int)(resize_factor * h->lrc_thresh);         // DF.cpp:318
+        if (h->conf_band && conf_band_fits(glo, h->disc_radius)) {
+            // the one-sweep kernel at the maps' resolution: ROI pixels from the band kernel, zeros outside (DF.cpp:187-190)
+            ConfBandArgs ba{dispL, sL, psL, dispR, sR, psR, clo, glo, rrx, thresh_lo, h->disc_radius, da.roll_off, 0};
+            HIP_TRY(launch_conf_band(ba, n_pairs, st));                    // DF.cpp:197-210
+            OutsideArgs oa{nullptr, 0, 0, 0, clo, glo};
+            HIP_TRY(launch_outside(oa, n_pairs, st));
+        } else {
+            HIP_TRY(launch_discontinuity(da, n_pairs, st));                // DF.cpp:204
+            LrcArgs la{dispL, sL, psL, dispR, sR, psR, cl, cr, clo, nullptr, 0, 0, 0, nullptr, nullptr, glo, rrx, thresh_lo, ORIENT_N};
+            HIP_TRY(launch_lrc_prologue(la, n_pairs, st));                 // DF.cpp:208-209
+        }
         ResizeArgs rc32{clo, (ptrdiff_t)dW * 4, (ptrdiff_t)(lo * 4), dW, dH, h->conf.p, (ptrdiff_t)W * 4, (ptrdiff_t)(hi * 4), W, H,
                         (double)dW / W, (double)dH / H, 1.0f, 0};
         HIP_TRY(launch_resize_linear(rc32, n_pairs, st));                  // DF.cpp:274

@@ -32,6 +32,11 @@ struct Geom {
 //   ORIENT_STRIP  (wave solver, Cvert) strip-major [pw/16][rh][16]
 enum Orient { ORIENT_N = 0, ORIENT_T = 1, ORIENT_PAIR = 2, ORIENT_STRIP = 3 };
 #define ADF_STRIP 16
+// Rows per tile of the pair plane: [rh/TR][pw/16][TR rows][U0 x16 | U1 x16] -- a strip visit of the column pass is
+// TR*128 contiguous bytes, a row of the row pass is 128-byte pieces at a TR*128-byte stride (power of two).
+#ifndef ADF_TILE_ROWS
+#define ADF_TILE_ROWS 2
+#endif
 
 // What the last sweep of a solve writes (fused epilogues).
 enum Epilogue {
@@ -181,7 +186,8 @@ int max_disc_radius();
 // float index of U0(i, j) inside an ORIENT_PAIR plane of pitch pw (U1 is ADF_STRIP floats further)
 __device__ __forceinline__ size_t pair_index(int i, int j, int pw)
 {
-    return (size_t)(i >> 1) * (size_t)(4 * pw) + (size_t)(((j >> 4) << 6) + ((i & 1) << 5) + (j & 15));
+    constexpr int TR = ADF_TILE_ROWS;
+    return (size_t)(i / TR) * (size_t)(2 * TR * pw) + (size_t)((j >> 4) * (32 * TR) + (i % TR) * 32 + (j & 15));
 }
 // float index of C(i, j) inside an ORIENT_STRIP plane of rh rows
 __device__ __forceinline__ size_t strip_index(int i, int j, int rh)

@@ -29,9 +29,10 @@ __global__ void __launch_bounds__(64, (M > ADF_H_TWO_WAVE_MAX && R > 1) ? 1 : 2)
     // R == 2: the two right-hand sides live in one pair plane, interleaved per 16 columns
     // ([U0 x16 | U1 x16] per strip, see fgs_wave_common.h): a row is 2*pitch contiguous floats
     constexpr bool PAIR = R > 1;
-    // (rows come in pairs: float4 #q of pair row r lives at (r/2)*(2*nvecU) + (q/8)*16 + (r%2)*8 + q%8)
-    const size_t offU = PAIR ? (size_t)blockIdx.y * 2 * a.plane + (size_t)(blockIdx.x >> 1) * (size_t)(4 * a.pitch) + (size_t)(blockIdx.x & 1) * 32 : off;
-#define ADF_PIDX(q) (PAIR ? ((((q) >> 3) << 4) + ((q) & 7)) : (q))
+    // (rows come in tiles of TR: float4 #q of pair row r lives at (r/TR)*(TR*nvecU) + (q/8)*8*TR + (r%TR)*8 + q%8)
+    constexpr int TR = ADF_TILE_ROWS;
+    const size_t offU = PAIR ? (size_t)blockIdx.y * 2 * a.plane + (size_t)(blockIdx.x / TR) * (size_t)(2 * TR * a.pitch) + (size_t)(blockIdx.x % TR) * 32 : off;
+#define ADF_PIDX(q) (PAIR ? ((((q) >> 3) * (8 * TR)) + ((q) & 7)) : (q))
     const int nvecU = PAIR ? 2 * nvec : nvec;
     constexpr int MQ = M / 4;
     float c[1][M], f0[1][M], f1[1][M];

@@ -83,10 +83,12 @@ __global__ void __launch_bounds__(VT) wave_vpass_kernel(WavePassArgs a)
     char* b0 = reinterpret_cast<char*>(a.U0 + (R > 1 ? 2 * pb : pb));
     char* b1 = (R > 1) ? b0 + 4 * VC : nullptr;
     const unsigned pitch_b = (unsigned)a.pitch * (R > 1 ? 8u : 4u);
-    // pair plane: [row pair][strip][row parity][32 floats]; r0 is even (every chunk length is)
-    static_assert(M % 2 == 0, "chunks must start on an even row");
-#define ADF_VSTEP(i) ((R > 1) ? (((i) & 1) ? (unsigned)a.pitch * 16u - 128u : 128u) : pitch_b)
-    const unsigned voff0 = (R > 1) ? ((unsigned)(r0 >> 1) * (unsigned)a.pitch * 4u + (unsigned)strip * (4u * VC) + 2u * xp) * 4u
+    // pair plane: [row tile][strip][row in tile][32 floats]; consecutive rows are 128 bytes apart inside a tile and a
+    // tile apart (minus the rows already walked) at a tile boundary -- which rows those are depends on the chunk's start
+    constexpr unsigned TR = ADF_TILE_ROWS;
+    const unsigned tile_b = 2u * TR * (unsigned)a.pitch * 4u;            // bytes from a tile to the next one
+#define ADF_VSTEP(i) ((R > 1) ? (((((unsigned)r0 + (unsigned)(i) + 1u) & (TR - 1u)) == 0u) ? tile_b - (TR - 1u) * 128u : 128u) : pitch_b)
+    const unsigned voff0 = (R > 1) ? (((unsigned)r0 / TR) * (2u * TR * (unsigned)a.pitch) + (unsigned)strip * (32u * TR) + ((unsigned)r0 % TR) * 32u + 2u * xp) * 4u
                                    : ((unsigned)r0 * (unsigned)a.pitch + (unsigned)col) * 4u;
     const unsigned pitch_c = 4u * VC;
     const unsigned coff0 = (((unsigned)strip * (unsigned)h + (unsigned)r0) * VC + 2u * xp) * 4u;
@@ -95,7 +97,7 @@ __global__ void __launch_bounds__(VT) wave_vpass_kernel(WavePassArgs a)
     // two-column templates in fgs_wave_common.h)
     v2f c[M], f0[M], f1[M];
     // row 0 of the column: always inside the planes
-    const unsigned safe = (R > 1) ? ((unsigned)strip * (4u * VC) + 2u * xp) * 4u : (unsigned)col * 4u;
+    const unsigned safe = (R > 1) ? ((unsigned)strip * (32u * TR) + 2u * xp) * 4u : (unsigned)col * 4u;
     const unsigned csafe = ((unsigned)strip * (unsigned)h * VC + 2u * xp) * 4u;
     {
         // Rows past the end of the column are loaded from row 0 of the same column (always inside the
