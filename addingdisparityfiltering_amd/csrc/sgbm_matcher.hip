@@ -156,12 +156,15 @@ __global__ void __launch_bounds__(512) sgbm_cost_kernel(CostArgs a)
 // ---------------------------------------------------------------------------------------------------------------
 // path costs
 // ---------------------------------------------------------------------------------------------------------------
-enum { DIR_TOP = 0, DIR_LEFT = 1, DIR_RIGHT = 2 };
+// DIR_TOP: first path, writes S; DIR_ADD: any direction of travel (dx, dy) in {-1,0,1}^2, adds to S; DIR_RIGHT: the last
+// path (from the right), adds, picks the winner
+enum { DIR_TOP = 0, DIR_ADD = 1, DIR_RIGHT = 2 };
 
 struct PathArgs {
     const int16_t* C; int16_t* S; size_t vol;
     int W, H, D, minD, minX1, w1, P1, P2, ur;
     int16_t* out; ptrdiff_t out_stride, out_pair;   // raw disparity map (elements)
+    int dx, dy;                                     // DIR_ADD: direction of travel
 };
 
 __device__ __forceinline__ int wave_min_i32(int v)
@@ -211,10 +214,26 @@ __global__ void __launch_bounds__(256) sgbm_path_kernel(PathArgs a)
     __shared__ int16_t sS[4][64 * DPL];                       // DIR_RIGHT: the pixel's S(d) for the sub-pixel fit
     extern __shared__ int16_t sOut[];                         // DIR_RIGHT: [4][w1] the scanline's results (written out coalesced)
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const int line = blockIdx.x * 4 + wv;                     // scanline: column (TOP) or row (LEFT / RIGHT)
-    const int nlines = DIR == DIR_TOP ? a.w1 : a.H;
+    const int line = blockIdx.x * 4 + wv;                     // scanline: a column (TOP), a row (RIGHT), any straight line (ADD)
+    // scanline -> first pixel (x0, y0), direction (dx, dy), length.  Diagonals: one line per pixel of the row the
+    // path enters through, then one per remaining pixel of the column it enters through.
+    int dx, dy, x0, y0, nlines, nsteps;
+    if (DIR == DIR_TOP) { dx = 0; dy = 1; nlines = a.w1; x0 = line; y0 = 0; nsteps = a.H; }
+    else if (DIR == DIR_RIGHT) { dx = -1; dy = 0; nlines = a.H; x0 = a.w1 - 1; y0 = line; nsteps = a.w1; }
+    else {
+        dx = a.dx; dy = a.dy;
+        const int ys = dy > 0 ? 0 : a.H - 1, xs = dx > 0 ? 0 : a.w1 - 1;
+        if (dy == 0) { nlines = a.H; x0 = xs; y0 = line; nsteps = a.w1; }
+        else if (dx == 0) { nlines = a.w1; x0 = line; y0 = ys; nsteps = a.H; }
+        else {
+            nlines = a.w1 + a.H - 1;
+            if (line < a.w1) { x0 = line; y0 = ys; }
+            else { const int j = line - a.w1 + 1; x0 = xs; y0 = dy > 0 ? j : a.H - 1 - j; }
+            const int nx = dx > 0 ? a.w1 - x0 : x0 + 1, ny = dy > 0 ? a.H - y0 : y0 + 1;
+            nsteps = min(nx, ny);
+        }
+    }
     if (line >= nlines) return;
-    const int nsteps = DIR == DIR_TOP ? a.H : a.w1;
     const int d0 = lane * DPL;
     const bool active = d0 < a.D;
     const size_t vol0 = (size_t)blockIdx.y * a.vol;
@@ -223,9 +242,7 @@ __global__ void __launch_bounds__(256) sgbm_path_kernel(PathArgs a)
     int16_t* S = a.S + vol0 + (active ? d0 : 0);
     // element offset of step t
     auto offs = [&](int t) -> size_t {
-        if (DIR == DIR_TOP) return ((size_t)t * a.w1 + line) * a.D;
-        const int x = DIR == DIR_LEFT ? t : a.w1 - 1 - t;
-        return ((size_t)line * a.w1 + x) * a.D;
+        return ((size_t)(y0 + t * dy) * a.w1 + (size_t)(x0 + t * dx)) * a.D;
     };
     int L[DPL];
 #pragma unroll
@@ -258,7 +275,7 @@ __global__ void __launch_bounds__(256) sgbm_path_kernel(PathArgs a)
             int st[DPL];
 #pragma unroll
             for (int k = 0; k < DPL; k++) st[k] = sat16i(s[k] + Ln[k]);
-            if (DIR == DIR_LEFT) {
+            if (DIR == DIR_ADD) {
                 store_costs<DPL>(S + o, active, st);
             } else {
                 // winner: the FIRST disparity with the smallest S (stereo_binary_sgbm.cpp:519-528)
@@ -395,17 +412,26 @@ hipError_t launch_cost(const CostArgs& a, int bs, dim3 grid, dim3 block, hipStre
 }
 
 template <int DPL>
-hipError_t launch_paths(const PathArgs& a, int n, hipStream_t st)
+hipError_t launch_paths(const PathArgs& a0, int mode, int n, hipStream_t st)
 {
-    hipLaunchKernelGGL((sgbm_path_kernel<DPL, DIR_TOP>), dim3((a.w1 + 3) / 4, n), dim3(256), 0, st, a);
-    hipLaunchKernelGGL((sgbm_path_kernel<DPL, DIR_LEFT>), dim3((a.H + 3) / 4, n), dim3(256), 0, st, a);
+    PathArgs a = a0;
+    hipLaunchKernelGGL((sgbm_path_kernel<DPL, DIR_TOP>), dim3((a.w1 + 3) / 4, n), dim3(256), 0, st, a);      // from above
+    // the other accumulating paths of the mode (direction of travel): MODE_SGBM_3WAY: from the left; MODE_SGBM: + the two
+    // upper diagonals; MODE_HH: + the three from below (stereo_binary_sgbm.cpp:173-186, 286-301)
+    static const int add[6][2] = { {1, 0}, {1, 1}, {-1, 1}, {-1, -1}, {0, -1}, {1, -1} };
+    const int nadd = mode == ADF_SGBM_MODE_3WAY ? 1 : mode == ADF_SGBM_MODE_SGBM ? 3 : 6;
+    for (int k = 0; k < nadd; k++) {
+        a.dx = add[k][0]; a.dy = add[k][1];
+        const int nlines = a.dy == 0 ? a.H : (a.dx == 0 ? a.w1 : a.w1 + a.H - 1);
+        hipLaunchKernelGGL((sgbm_path_kernel<DPL, DIR_ADD>), dim3((nlines + 3) / 4, n), dim3(256), 0, st, a);
+    }
     const size_t lds_out = (size_t)a.w1 * 4 * sizeof(int16_t);
     if (lds_out > 48 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(sgbm_path_kernel<DPL, DIR_RIGHT>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_out);
         if (e != hipSuccess) return e;
     }
-    hipLaunchKernelGGL((sgbm_path_kernel<DPL, DIR_RIGHT>), dim3((a.H + 3) / 4, n), dim3(256), lds_out, st, a);
+    hipLaunchKernelGGL((sgbm_path_kernel<DPL, DIR_RIGHT>), dim3((a.H + 3) / 4, n), dim3(256), lds_out, st, a);   // from the right + winner
     return hipGetLastError();
 }
 
@@ -488,7 +514,8 @@ static int sgbm_check(const adf_sgbm* h, int n, const void* l, const void* r, co
     if (cn != 1 && cn != 3) return sg_fail(ADF_EBADARG, "views must be CV_8UC1 or CV_8UC3");
     if (W <= 0 || H <= 0 || ls < (ptrdiff_t)W * cn || rs < (ptrdiff_t)W * cn || dstr < (ptrdiff_t)W * 2) return sg_fail(ADF_ESIZE, "bad size or stride");
     if ((dstr & 1) || (reinterpret_cast<uintptr_t>(d) & 1)) return sg_fail(ADF_ESIZE, "disparity rows must be 2-byte aligned");
-    if (h->mode != ADF_SGBM_MODE_3WAY) return sg_fail(ADF_EBADARG, "only StereoSGBM::MODE_SGBM_3WAY (the sample's mode) is implemented on the device");
+    if (h->mode != ADF_SGBM_MODE_3WAY && h->mode != ADF_SGBM_MODE_SGBM && h->mode != ADF_SGBM_MODE_HH)
+        return sg_fail(ADF_EBADARG, "mode must be StereoSGBM::MODE_SGBM, MODE_HH or MODE_SGBM_3WAY");
     if (h->num_disp <= 0 || h->num_disp % 16) return sg_fail(ADF_EBADARG, "numDisparities must be positive and divisible by 16");
     if (h->num_disp > 512) return sg_fail(ADF_EBADARG, "numDisparities above 512 is not supported");
     const int bs = h->block > 0 ? h->block : 5;
@@ -559,9 +586,9 @@ extern "C" int adf_sgbm_compute_device(adf_sgbm_t* h, int n_pairs,
             const dim3 cgrid(w1, (H + rpb - 1) / rpb, n), cblock((D + 63) / 64 * 64);
             hipError_t e = cn == 1 ? launch_cost<1>(ca, bs, cgrid, cblock, st) : launch_cost<3>(ca, bs, cgrid, cblock, st);
             if (e != hipSuccess) return sg_fail(ADF_EHIP, hipGetErrorString(e));
-            PathArgs pa{Cv, Sv, volp, W, H, D, minD, minX1, w1, P1, P2, ur, raw, (ptrdiff_t)W, (ptrdiff_t)raw_el};
-            e = D <= 64 ? launch_paths<1>(pa, n, st) : D <= 128 ? launch_paths<2>(pa, n, st)
-              : D <= 256 ? launch_paths<4>(pa, n, st) : launch_paths<8>(pa, n, st);
+            PathArgs pa{Cv, Sv, volp, W, H, D, minD, minX1, w1, P1, P2, ur, raw, (ptrdiff_t)W, (ptrdiff_t)raw_el, 0, 0};
+            e = D <= 64 ? launch_paths<1>(pa, h->mode, n, st) : D <= 128 ? launch_paths<2>(pa, h->mode, n, st)
+              : D <= 256 ? launch_paths<4>(pa, h->mode, n, st) : launch_paths<8>(pa, h->mode, n, st);
             if (e != hipSuccess) return sg_fail(ADF_EHIP, hipGetErrorString(e));
         }
         MedianArgs ma{raw, (ptrdiff_t)W, (ptrdiff_t)raw_el, out, disp_stride / 2, disp_pair_stride / 2, W, H};

@@ -418,7 +418,8 @@ class StereoBM(StereoMatcher):
 class StereoSGBM(StereoMatcher):
     """cv::StereoSGBM's accessors plus compute() on the device (csrc/sgbm_matcher.hip): the published semi-global
     algorithm with three paths (MODE_SGBM_3WAY, the mode the reference's sample selects:
-    samples/disparity_filtering.cpp:166-176), bit-exact against oracle/adf_oracle_sgbm.c; parity unpinned at calib3d."""
+    samples/disparity_filtering.cpp:166-176), five (MODE_SGBM) or eight (MODE_HH), bit-exact against
+    oracle/adf_oracle_sgbm.c; parity unpinned at calib3d."""
     MODE_SGBM, MODE_HH, MODE_SGBM_3WAY = 0, 1, 2
 
     def __init__(self, minDisparity=0, numDisparities=16, blockSize=3, P1=0, P2=0, mode=0, preFilterCap=0):
@@ -454,10 +455,11 @@ class StereoSGBM(StereoMatcher):
     def compute(self, left, right, disparity=None):
         """StereoMatcher::compute: CV_8UC1 / CV_8UC3 views (H,W[,3]) or a batch (N,H,W[,3]) -> CV_16SC1 disparity*16,
         invalid pixels (minDisparity-1)*16.  torch CUDA tensors are matched where they are, asynchronously on torch's
-        current stream; numpy arrays take the host entry point.  Only MODE_SGBM_3WAY is built; the matcher's own
-        left-right check and speckle filter are not (the filter factory switches both off, DF.cpp:389-390)."""
-        if self.mode != StereoSGBM.MODE_SGBM_3WAY:
-            raise AdfError(_lib.ADF_EBADARG, "only StereoSGBM.MODE_SGBM_3WAY (the sample's mode) is implemented on the device")
+        current stream; numpy arrays take the host entry point.  MODE_SGBM_3WAY (3 paths, the sample's), MODE_SGBM (5)
+        and MODE_HH (8); the matcher's own left-right check and speckle filter are not built (the filter factory
+        switches both off, DF.cpp:389-390)."""
+        if self.mode not in (StereoSGBM.MODE_SGBM, StereoSGBM.MODE_HH, StereoSGBM.MODE_SGBM_3WAY):
+            raise AdfError(_lib.ADF_EBADARG, "mode must be StereoSGBM.MODE_SGBM, MODE_HH or MODE_SGBM_3WAY")
         if self.disp12MaxDiff < 1000000:
             raise AdfError(_lib.ADF_EBADARG, "disp12MaxDiff (left-right check inside the matcher) is not implemented: "
                                              "createDisparityWLSFilter sets it to 1000000")

@@ -290,13 +290,15 @@ int adf_bm_compute_host(adf_bm_t* h, int n_pairs,
  * cv::StereoSGBM as the reference's sample configures it (samples/disparity_filtering.cpp:166-176, 229-235:
  * P1 = 24*w*w, P2 = 96*w*w, preFilterCap 63, MODE_SGBM_3WAY) and as its factories expect it
  * (disparity_filters.cpp:404-409, 432-445): the published semi-global algorithm (Hirschmueller 2008) with the
- * Birchfield-Tomasi block cost and three paths (left, top, right), sub-pixel fit, 3x3 median of the result;
+ * Birchfield-Tomasi block cost and three paths (MODE_SGBM_3WAY: left, top, right; MODE_SGBM: five, MODE_HH: eight --
+ * modules/stereo/src/stereo_binary_sgbm.cpp:173-186, 286-301 is the in-tree statement of the path sets), sub-pixel fit,
+ * 3x3 median of the result;
  * CV_16SC1 with 4 fractional bits, invalid pixels (minDisparity-1)*16, matchable columns
  * [max(minDisparity+numDisparities,0), W+min(minDisparity,0)).  The class itself lives in OpenCV's calib3d (outside
  * the reference tree: parity unpinned); results are bit-exact against oracle/adf_oracle_sgbm.c and anchored on the
  * reference's own semi-global test (modules/stereo/test/test_block_matching.cpp:157-238).  Not implemented, and not
  * reachable from the filter (its factories switch them off): the matcher's own left-right check (disp12MaxDiff) and
- * speckle filter; MODE_SGBM / MODE_HH.  Limits: numDisparities <= 512, blockSize odd <= 11. */
+ * speckle filter.  Limits: numDisparities <= 512, blockSize odd <= 11. */
 #define ADF_SGBM_MODE_SGBM 0
 #define ADF_SGBM_MODE_HH 1
 #define ADF_SGBM_MODE_3WAY 2 /* StereoSGBM::MODE_SGBM_3WAY */

@@ -314,7 +314,7 @@ inline Ptr<StereoBM> createRightMatcher(const Ptr<StereoBM>& matcher_left)
 
 // ---------------------------------------------------------------------------------------------------------
 // Semi-global matcher feeding the filter: cv::StereoSGBM's accessor names over adf_sgbm_*, the
-// sample's other producer (samples/disparity_filtering.cpp:166-176).  Only MODE_SGBM_3WAY is built on the device.
+// sample's other producer (samples/disparity_filtering.cpp:166-176).  MODE_SGBM_3WAY (the sample's), MODE_SGBM, MODE_HH.
 // ---------------------------------------------------------------------------------------------------------
 class StereoSGBM {
     adf_sgbm_t* h_ = nullptr;

@@ -45,7 +45,7 @@ class SGBMParams(C.Structure):
     ]
 
 
-SGBM_MODE_SGBM, SGBM_MODE_HH, SGBM_MODE_3WAY = 0, 1, 2
+SGBM_MODE_SGBM, SGBM_MODE_HH, SGBM_MODE_3WAY, SGBM_MODE_3WAY_GENERIC = 0, 1, 2, 3
 
 
 class BMParams(C.Structure):

@@ -161,6 +161,7 @@ int adf_oracle_bm_compute(const adf_oracle_bm_params* p, const uint8_t* left, pt
 #define ADF_SGBM_MODE_SGBM 0
 #define ADF_SGBM_MODE_HH 1
 #define ADF_SGBM_MODE_3WAY 2   /* StereoSGBM::MODE_SGBM_3WAY, the sample's mode (samples/disparity_filtering.cpp:170) */
+#define ADF_SGBM_MODE_3WAY_GENERIC 3   /* test hook: the three paths of MODE_3WAY through the general multi-path code */
 typedef struct adf_oracle_sgbm_params {
     int min_disparity;      /* right matcher: -(min+num)+1, disparity_filters.cpp:435 */
     int num_disparities;    /* multiple of 16 */
@@ -168,7 +169,7 @@ typedef struct adf_oracle_sgbm_params {
     int P1, P2;             /* sample: 24*w*w, 96*w*w; 0 -> 2 / 5; P2 >= P1+1 */
     int prefilter_cap;      /* sample: 63 */
     int uniqueness_ratio;   /* forced to 0 by the filter factory (disparity_filters.cpp:406,436); < 0 -> 10 */
-    int mode;               /* ADF_SGBM_MODE_3WAY only */
+    int mode;               /* ADF_SGBM_MODE_3WAY (3 paths), ADF_SGBM_MODE_SGBM (5), ADF_SGBM_MODE_HH (8) */
 } adf_oracle_sgbm_params;
 /* (value, min, max over the half-sample neighbours) of every signal of every pixel: rec[H][W][2cn][3] */
 void adf_oracle_sgbm_signals(const uint8_t* img, ptrdiff_t stride, int cn, int W, int H, int prefilter_cap, uint8_t* rec);

@@ -22,7 +22,8 @@
  *   4. path costs L_r(p,d) = C(p,d) + min(L_r(p-r,d), L_r(p-r,d-1)+P1, L_r(p-r,d+1)+P1, min_k L_r(p-r,k)+P2)
  *      - min_k L_r(p-r,k) (stereo_binary_sgbm.cpp:286-301, 419-446), neighbours outside [0,D) = SHRT_MAX (:323-324),
  *      path buffers start at zero (:191-194), costs kept in 16 bits with saturation; MODE_SGBM_3WAY uses three
- *      paths: from the left, from the top, from the right;
+ *      paths: from the left, from the top, from the right; MODE_SGBM five (left, up-left, up, up-right, right: the
+ *      forward sweep of :286-446 plus the backward one of :456-534), MODE_HH eight (two mirrored passes, :173-186);
  *   5. S = sum of the three paths; winner = the FIRST disparity with the smallest S (:519-528, strict <);
  *      uniqueness test (:543-547); sub-pixel parabola fit with 4 fractional bits (:584-591); result
  *      d + minDisparity*16 (:596); pixels outside [minX1, maxX1) and rejected ones hold (minDisparity-1)*16
@@ -131,7 +132,8 @@ static int sgbm_setup(const adf_oracle_sgbm_params* p, int W, int H, int cn, sgb
 {
     if (!p || W <= 0 || H <= 0 || (cn != 1 && cn != 3)) return -1;
     if (p->num_disparities <= 0 || p->num_disparities % 16) return -1;
-    if (p->mode != ADF_SGBM_MODE_3WAY) return -2;
+    if (p->mode != ADF_SGBM_MODE_3WAY && p->mode != ADF_SGBM_MODE_SGBM && p->mode != ADF_SGBM_MODE_HH &&
+        p->mode != ADF_SGBM_MODE_3WAY_GENERIC) return -2;
     const int bs = p->block_size > 0 ? p->block_size : 5;
     if (!(bs & 1)) return -1;
     g->minD = p->min_disparity; g->D = p->num_disparities; g->W = W; g->H = H; g->cn = cn;
@@ -191,6 +193,86 @@ static inline int path_step(const int16_t* Cp, const int16_t* Lprev, int minprev
     return mn;
 }
 
+/* Formula 13 along an arbitrary direction of travel (dx, dy), added into the volume S[y][x][d] (saturating):
+ * the pixel before (x, y) on the path is (x - dx, y - dy); a path entering the matchable area starts from zeros
+ * (the border cells of the Lr / minLr buffers are cleared, stereo_binary_sgbm.cpp:191-194, 279-283).  MODE_SGBM sums
+ * five such paths -- from the left, up-left, up, up-right (the four of the forward sweep, :286-301) and from the
+ * right (the backward sweep of the single-pass mode, :456-534); MODE_HH eight (the second pass mirrors the first, :173-186). */
+static void add_path(const int16_t* C, int16_t* S, int H, int w1, int D, int dx, int dy, int P1, int P2)
+{
+    const size_t LW = (size_t)D + 2;
+    int16_t* prev = (int16_t*)malloc(sizeof(int16_t) * LW * (size_t)w1);
+    int16_t* cur = (int16_t*)malloc(sizeof(int16_t) * LW * (size_t)w1);
+    int* mprev = (int*)malloc(sizeof(int) * (size_t)w1);
+    int* mcur = (int*)malloc(sizeof(int) * (size_t)w1);
+    int16_t* zero = (int16_t*)calloc(LW, sizeof(int16_t));
+    zero[0] = zero[D + 1] = SGBM_MAX_COST;
+    const int ystart = dy >= 0 ? 0 : H - 1, ystep = dy >= 0 ? 1 : -1;
+    const int xstart = dx >= 0 ? 0 : w1 - 1, xstep = dx >= 0 ? 1 : -1;
+    for (int yi = 0, y = ystart; yi < H; yi++, y += ystep) {
+        for (int xi = 0, x = xstart; xi < w1; xi++, x += xstep) {
+            const int px = x - dx;
+            const int16_t* Lp = zero; int mp = 0;
+            if (dy == 0) { if (xi > 0) { Lp = cur + LW * (size_t)px; mp = mcur[px]; } }
+            else if (yi > 0 && px >= 0 && px < w1) { Lp = prev + LW * (size_t)px; mp = mprev[px]; }
+            const size_t o = ((size_t)y * w1 + x) * D;
+            mcur[x] = path_step(C + o, Lp, mp, cur + LW * (size_t)x, D, P1, P2);
+            for (int d = 0; d < D; d++) S[o + d] = sat_s16((int)S[o + d] + (int)cur[LW * (size_t)x + d + 1]);
+        }
+        { int16_t* t = prev; prev = cur; cur = t; int* m = mprev; mprev = mcur; mcur = m; }
+    }
+    free(prev); free(cur); free(mprev); free(mcur); free(zero);
+}
+
+/* MODE_SGBM / MODE_HH: whole volumes in memory (tests and small images). */
+static void sgbm_multipath(const sgbm_geom* g, int mode, int P1, int P2, int ur, int minD, int16_t* tmp)
+{
+    const int D = g->D, w1 = g->width1, H = g->H, W = g->W;
+    const size_t rowsz = (size_t)w1 * D, K = (size_t)(2 * g->SH2 + 1);
+    int* pix = (int*)malloc(sizeof(int) * rowsz);
+    int* hs = (int*)malloc(sizeof(int) * rowsz * (size_t)H);
+    int16_t* C = (int16_t*)malloc(sizeof(int16_t) * rowsz * (size_t)H);
+    int16_t* S = (int16_t*)calloc(rowsz * (size_t)H, sizeof(int16_t));
+    (void)K;
+    for (int y = 0; y < H; y++) hsum_row(g, y, pix, hs + rowsz * (size_t)y);
+    for (int y = 0; y < H; y++)
+        for (size_t i = 0; i < rowsz; i++) {
+            int s = 0;
+            for (int k = -g->SH2; k <= g->SH2; k++) {
+                int yy = y + k; yy = yy < 0 ? 0 : (yy > H - 1 ? H - 1 : yy);
+                s += hs[rowsz * (size_t)yy + i];
+            }
+            C[rowsz * (size_t)y + i] = sat_s16(s);
+        }
+    static const int dirs[8][2] = { {1, 0}, {1, 1}, {0, 1}, {-1, 1}, {-1, 0}, {-1, -1}, {0, -1}, {1, -1} };
+    const int ndirs = mode == ADF_SGBM_MODE_HH ? 8 : 5;
+    for (int k = 0; k < ndirs; k++) {
+        if (mode == ADF_SGBM_MODE_3WAY_GENERIC && (k & 1)) continue;   /* test hook: left, up, right only */
+        add_path(C, S, H, w1, D, dirs[k][0], dirs[k][1], P1, P2);
+    }
+    for (int y = 0; y < H; y++) {
+        int16_t* out = tmp + (size_t)y * W;
+        for (int x = 0; x < w1; x++) {
+            const int16_t* Sp = S + ((size_t)y * w1 + x) * D;
+            int minS = SGBM_MAX_COST, best = -1;
+            for (int d = 0; d < D; d++) if (Sp[d] < minS) { minS = Sp[d]; best = d; }   /* :519-528, 536-546 */
+            if (best < 0) continue;
+            int d;
+            for (d = 0; d < D; d++)
+                if (Sp[d] * (100 - ur) < minS * 100 && abs(best - d) > 1) break;
+            if (d < D) continue;
+            d = best;
+            if (0 < d && d < D - 1) {
+                const int denom2 = imax2(Sp[d - 1] + Sp[d + 1] - 2 * Sp[d], 1);
+                d = d * DISP_SCALE + ((Sp[d - 1] - Sp[d + 1]) * DISP_SCALE + denom2) / (denom2 * 2);
+            } else
+                d *= DISP_SCALE;
+            out[x + g->minX1] = (int16_t)(d + minD * DISP_SCALE);
+        }
+    }
+    free(pix); free(hs); free(C); free(S);
+}
+
 /* Step 6: cv::medianBlur(disp, disp, 3) on CV_16SC1, border replicated. */
 void adf_oracle_median3_16s(const int16_t* src, ptrdiff_t sstride, int16_t* dst, ptrdiff_t dstride, int W, int H)
 {
@@ -224,7 +306,15 @@ int adf_oracle_sgbm_compute(const adf_oracle_sgbm_params* p, const uint8_t* img1
     const int16_t invalid = (int16_t)((minD - 1) * DISP_SCALE);
     int16_t* tmp = (int16_t*)malloc(sizeof(int16_t) * (size_t)W * H);
     for (size_t i = 0; i < (size_t)W * H; i++) tmp[i] = invalid;
-    if (w1 > 0) {
+    if (w1 > 0 && p->mode != ADF_SGBM_MODE_3WAY) {
+        uint8_t* r1 = (uint8_t*)malloc((size_t)W * H * 6 * cn);
+        uint8_t* r2 = (uint8_t*)malloc((size_t)W * H * 6 * cn);
+        adf_oracle_sgbm_signals(img1, s1, cn, W, H, p->prefilter_cap, r1);
+        adf_oracle_sgbm_signals(img2, s2, cn, W, H, p->prefilter_cap, r2);
+        g.r1 = r1; g.r2 = r2;
+        sgbm_multipath(&g, p->mode, P1, P2, ur, minD, tmp);
+        free(r1); free(r2);
+    } else if (w1 > 0) {
         uint8_t* r1 = (uint8_t*)malloc((size_t)W * H * 6 * cn);
         uint8_t* r2 = (uint8_t*)malloc((size_t)W * H * 6 * cn);
         adf_oracle_sgbm_signals(img1, s1, cn, W, H, p->prefilter_cap, r1);

@@ -30,6 +30,8 @@ if [ "$solver" = wave ]; then
   python3 tools/sgbm_time.py 1920 1080 160 3 4 3 >> gpurun_out/${round}_sgbm_times.txt 2>&1
   python3 tools/sgbm_time.py 1242 375 128 3 16 1 >> gpurun_out/${round}_sgbm_times.txt 2>&1
   python3 tools/sgbm_time.py 1920 1080 160 3 1 1 >> gpurun_out/${round}_sgbm_times.txt 2>&1
+  python3 tools/sgbm_time.py 1920 1080 160 3 4 1 0 >> gpurun_out/${round}_sgbm_times.txt 2>&1
+  python3 tools/sgbm_time.py 1920 1080 160 3 4 1 1 >> gpurun_out/${round}_sgbm_times.txt 2>&1
 fi
 find ${tag}_stats ${tag}_pmc_fetch ${tag}_pmc_write -name "*.csv" | sort
 cat ${tag}_bench_n1.json

@@ -160,8 +160,8 @@ int main()
                                      exp.ptr<int16_t>(), (ptrdiff_t)exp.step, nullptr) == 0);
         EXPECT(std::memcmp(sout.data, exp.data, (size_t)H * exp.step) == 0);
         threw = false;
-        try { Ptr<StereoSGBM> q = StereoSGBM::create(0, 16, 3); q->setDisp12MaxDiff(1000000); q->compute(left, right, sdl); }
-        catch (const Exception&) { threw = true; }                             // default mode MODE_SGBM is not built on the device
+        try { Ptr<StereoSGBM> q = StereoSGBM::create(0, 16, 3); q->compute(left, right, sdl); }
+        catch (const Exception&) { threw = true; }                             // create's default disp12MaxDiff = 0: the matcher's own left-right check is not built
         EXPECT(threw);
     }
     {   // error behaviour: exceptions like CV_Assert / CV_Error

@@ -77,7 +77,8 @@ def test_matcher_factories_host_logic():
         adf.createRightMatcher(adf.StereoMatcher())
     with pytest.raises(adf.AdfError):
         adf.createDisparityWLSFilter(adf.StereoMatcher())
-    with pytest.raises(adf.AdfError):                       # only the sample's mode (MODE_SGBM_3WAY) is built on the device
+    right.setMode(7)
+    with pytest.raises(adf.AdfError):                       # unknown mode
         right.compute(np.zeros((8, 8), np.uint8), np.zeros((8, 8), np.uint8))
     fresh = adf.StereoSGBM.create(0, 16, 3)
     fresh.setMode(adf.StereoSGBM.MODE_SGBM_3WAY)

@@ -11,10 +11,10 @@ from test_oracle_sgbm import _pair, ref_error_level
 pytestmark = pytest.mark.gpu
 
 
-def _sgbm(adf, nd, bs, md=0, P1=None, P2=None, cap=63, ur=0):
+def _sgbm(adf, nd, bs, md=0, P1=None, P2=None, cap=63, ur=0, mode=2):
     m = adf.StereoSGBM.create(md, nd, bs)
     m.setP1(24 * bs * bs if P1 is None else P1); m.setP2(96 * bs * bs if P2 is None else P2)
-    m.setPreFilterCap(cap); m.setUniquenessRatio(ur); m.setMode(adf.StereoSGBM.MODE_SGBM_3WAY)
+    m.setPreFilterCap(cap); m.setUniquenessRatio(ur); m.setMode(mode)
     m.setDisp12MaxDiff(1000000); m.setSpeckleWindowSize(0)          # what createDisparityWLSFilter sets (DF.cpp:389-390)
     return m
 
@@ -121,7 +121,7 @@ def test_matcher_errors(adf):
     for nd, bs in ((24, 3), (16, 4), (16, 13), (528, 3)):
         with pytest.raises(adf.AdfError):
             _sgbm(adf, nd, bs).compute(a, b)
-    m = _sgbm(adf, 16, 3); m.setMode(adf.StereoSGBM.MODE_SGBM)
+    m = _sgbm(adf, 16, 3); m.setMode(5)
     with pytest.raises(adf.AdfError):
         m.compute(a, b)
     m = _sgbm(adf, 16, 3); m.setDisp12MaxDiff(1)
@@ -129,3 +129,45 @@ def test_matcher_errors(adf):
         m.compute(a, b)
     with pytest.raises(adf.AdfError):
         _sgbm(adf, 16, 3).compute(a, b[:, :-1])
+
+
+def test_random_parameters_bit_exact(adf, oracle):
+    """Seeded fuzz over sizes and every parameter of the matcher (guards the kernels' template / lane arithmetic)."""
+    rng = np.random.default_rng(77)
+    for case in range(30):
+        bs = int(rng.choice([1, 3, 5, 7, 9, 11]))
+        nd = 16 * int(rng.integers(1, 13))
+        md = int(rng.integers(-nd - 6, 20))
+        cn = int(rng.choice([1, 1, 3]))
+        H = int(rng.integers(2, 60)); W = int(rng.integers(max(8, nd // 2), nd + 260))
+        P1 = int(rng.choice([0, 8, 72, 216, 600])); P2 = int(rng.choice([0, 32, 288, 864, 2400]))
+        cap = int(rng.choice([0, 15, 31, 63])); ur = int(rng.choice([0, 0, 5, 15, 40]))
+        a, b = _pair(3000 + case, H, W, cn, shift=int(rng.integers(0, 14)))
+        got = _sgbm(adf, nd, bs, md, P1, P2, cap, ur).compute(a, b)
+        exp = oracle.sgbm_compute(a, b, nd, bs, md, P1, P2, cap, ur)
+        assert np.array_equal(got, exp), (case, H, W, cn, nd, bs, md, P1, P2, cap, ur)
+
+
+@pytest.mark.parametrize("mode", [0, 1])
+@pytest.mark.parametrize("H,W,nd,bs,md,P1,P2,cap,ur,cn", [
+    (40, 120, 32, 3, 0, 216, 864, 63, 0, 1),       # wider than tall: diagonals leave through the bottom
+    (150, 70, 16, 5, -15, 10, 100, 31, 10, 1),     # taller than the matchable area is wide: they leave through the sides
+    (33, 90, 160, 3, 0, 72, 288, 63, 0, 1),        # narrower matchable area than disparities; idle lanes
+    (27, 100, 48, 7, -20, 50, 200, 40, 0, 3),      # 3 channels, range straddling zero
+    (1, 60, 16, 3, 0, 72, 288, 63, 0, 1),          # a single row: every vertical / diagonal path is one pixel long
+    (50, 17, 16, 1, 0, 0, 0, 0, 0, 1),             # a single matchable column
+])
+def test_five_and_eight_path_modes_bit_exact(adf, oracle, mode, H, W, nd, bs, md, P1, P2, cap, ur, cn):
+    """cv::StereoSGBM's default MODE_SGBM (left, up-left, up, up-right, right) and MODE_HH (all eight directions)."""
+    a, b = _pair(H * W + nd + mode, H, W, cn, shift=5)
+    got = _sgbm(adf, nd, bs, md, P1, P2, cap, ur, mode).compute(a, b)
+    exp = oracle.sgbm_compute(a, b, nd, bs, md, P1, P2, cap, ur, mode=mode)
+    assert np.array_equal(got, exp)
+
+
+def test_modes_on_the_reference_fixture(adf, oracle):
+    left, right, gt = load_tsukuba()
+    for mode in (0, 1, 2):
+        got = _sgbm(adf, 16, 3, 0, 216, 864, 63, 0, mode).compute(left, right)
+        assert np.array_equal(got, oracle.sgbm_compute(left, right, 16, 3, 0, 216, 864, 63, 0, mode=mode))
+        assert ref_error_level(gt, got) <= 10.0

@@ -20,7 +20,12 @@ def ref_error_level(gt, disp16):
     return 100.0 * bad.sum() / gt.size
 
 
-def naive_sgbm(img1, img2, nd, bs, md=0, P1=0, P2=0, cap=0, ur=0):
+DIRS = {2: [(1, 0), (0, 1), (-1, 0)],                                                       # MODE_SGBM_3WAY
+        0: [(1, 0), (1, 1), (0, 1), (-1, 1), (-1, 0)],                                      # MODE_SGBM
+        1: [(1, 0), (1, 1), (0, 1), (-1, 1), (-1, 0), (-1, -1), (0, -1), (1, -1)]}          # MODE_HH
+
+
+def naive_sgbm(img1, img2, nd, bs, md=0, P1=0, P2=0, cap=0, ur=0, mode=2):
     """Independent direct statement (numpy, whole cost volume in memory) of the definition in adf_oracle_sgbm.c."""
     a = img1.astype(np.int64); b = img2.astype(np.int64)
     if a.ndim == 2:
@@ -72,18 +77,21 @@ def naive_sgbm(img1, img2, nd, bs, md=0, P1=0, P2=0, cap=0, ur=0):
         L = np.clip(L, -32768, SHRT_MAX)
         return L, L.min()
 
-    Ltop = np.zeros((w1, nd), np.int64); mtop = np.zeros(w1, np.int64)
+    # every path of the mode: L volume by direct recursion on the pixel before (x - dx, y - dy); zeros outside
+    S = np.zeros((H, w1, nd), np.int64)
+    for dx, dy in DIRS[mode]:
+        L = np.zeros((H, w1, nd), np.int64); M = np.zeros((H, w1), np.int64)
+        for y in (range(H) if dy >= 0 else range(H - 1, -1, -1)):
+            for x in (range(w1) if dx >= 0 else range(w1 - 1, -1, -1)):
+                px, py = x - dx, y - dy
+                if 0 <= px < w1 and 0 <= py < H:
+                    L[y, x], M[y, x] = step(Cv[y, x], L[py, px], M[py, px])
+                else:
+                    L[y, x], M[y, x] = step(Cv[y, x], np.zeros(nd, np.int64), 0)
+        S = np.clip(S + L, -32768, SHRT_MAX)
     for y in range(H):
-        S = np.zeros((w1, nd), np.int64)
-        L = np.zeros(nd, np.int64); m = 0
         for x in range(w1):
-            Ltop[x], mtop[x] = step(Cv[y, x], Ltop[x], mtop[x])
-            L, m = step(Cv[y, x], L, m)
-            S[x] = np.clip(L + Ltop[x], -32768, SHRT_MAX)
-        L = np.zeros(nd, np.int64); m = 0
-        for x in range(w1 - 1, -1, -1):
-            L, m = step(Cv[y, x], L, m)
-            Sp = np.clip(S[x] + L, -32768, SHRT_MAX)
+            Sp = S[y, x]
             best = int(np.argmin(Sp)); ms = int(Sp[best])            # argmin: first minimum
             if ms >= SHRT_MAX:
                 continue
@@ -131,6 +139,24 @@ def test_oracle_equals_direct_statement(oracle, H, W, nd, bs, md, P1, P2, cap, u
     assert np.array_equal(got, naive_median3(exp_raw))
     if W - max(md + nd, 0) + min(md, 0) <= 0:
         assert (raw == (md - 1) * 16).all()
+    # the three paths of MODE_3WAY through the oracle's general multi-path code give the same map
+    assert np.array_equal(oracle.sgbm_compute(a, b, nd, bs, md, P1, P2, cap, ur, mode=oracle.SGBM_MODE_3WAY_GENERIC), got)
+
+
+@pytest.mark.parametrize("mode", [0, 1])
+@pytest.mark.parametrize("H,W,nd,bs,md,P1,P2,cap,ur,cn", [
+    (12, 40, 16, 3, 0, 72, 288, 63, 0, 1),
+    (9, 36, 16, 5, -15, 10, 100, 31, 10, 1),
+    (7, 30, 16, 3, 3, 216, 864, 63, 0, 3),
+    (15, 28, 16, 1, 0, 0, 0, 0, 0, 1),          # taller than the matchable area is wide: diagonals leave through the sides
+])
+def test_five_and_eight_path_modes_equal_direct_statement(oracle, mode, H, W, nd, bs, md, P1, P2, cap, ur, cn):
+    """MODE_SGBM (left, up-left, up, up-right, right) and MODE_HH (all eight) against the direct recursion."""
+    a, b = _pair(H * W + nd + mode, H, W, cn)
+    got, raw = oracle.sgbm_compute(a, b, nd, bs, md, P1, P2, cap, ur, mode=mode, want_raw=True)
+    exp_raw = naive_sgbm(a, b, nd, bs, md, P1, P2, cap, ur, mode=mode)
+    assert np.array_equal(raw, exp_raw)
+    assert np.array_equal(got, naive_median3(exp_raw))
 
 
 def test_block_costs_helper(oracle):
