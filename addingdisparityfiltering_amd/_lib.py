@@ -93,6 +93,8 @@ SYMBOLS = [
     ("adf_sgbm_get_device", _i, [_vp, C.POINTER(_i)]),
     ("adf_sgbm_set_params", _i, [_vp] + [_i] * 8),
     ("adf_sgbm_get_params", _i, [_vp] + [C.POINTER(_i)] * 8),
+    ("adf_sgbm_set_disp12_max_diff", _i, [_vp, _i]),
+    ("adf_sgbm_get_disp12_max_diff", _i, [_vp, C.POINTER(_i)]),
     ("adf_sgbm_compute_device", _i, [_vp, _i, _vp, _pd, _pd, _vp, _pd, _pd, _i, _i, _i, _vp, _pd, _pd, _vp]),
     ("adf_sgbm_compute_host", _i, [_vp, _i, _vp, _pd, _pd, _vp, _pd, _pd, _i, _i, _i, _vp, _pd, _pd]),
 ]

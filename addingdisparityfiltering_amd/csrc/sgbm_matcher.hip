@@ -165,6 +165,7 @@ struct PathArgs {
     int W, H, D, minD, minX1, w1, P1, P2, ur;
     int16_t* out; ptrdiff_t out_stride, out_pair;   // raw disparity map (elements)
     int dx, dy;                                     // DIR_ADD: direction of travel
+    int disp12;                                     // DIR_RIGHT: the matcher's own left-right check (>= 100000: off)
 };
 
 __device__ __forceinline__ int wave_min_i32(int v)
@@ -212,7 +213,8 @@ template <int DPL, int DIR>
 __global__ void __launch_bounds__(256) sgbm_path_kernel(PathArgs a)
 {
     __shared__ int16_t sS[4][64 * DPL];                       // DIR_RIGHT: the pixel's S(d) for the sub-pixel fit
-    extern __shared__ int16_t sOut[];                         // DIR_RIGHT: [4][w1] the scanline's results (written out coalesced)
+    extern __shared__ int16_t sOut[];                         // DIR_RIGHT: [4][w1] the scanline's results (written out coalesced),
+                                                              // then [4][W] disp2 and [4][W] its cost (left-right check)
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int line = blockIdx.x * 4 + wv;                     // scanline: a column (TOP), a row (RIGHT), any straight line (ADD)
     // scanline -> first pixel (x0, y0), direction (dx, dy), length.  Diagonals: one line per pixel of the row the
@@ -250,6 +252,13 @@ __global__ void __launch_bounds__(256) sgbm_path_kernel(PathArgs a)
     int minprev = 0;
     const int16_t invalid = (int16_t)((a.minD - 1) * SG_DISP_SCALE);
     int16_t* myOut = sOut + wv * a.w1;
+    // the matcher's own left-right check (stereo_binary_sgbm.cpp:548-556, 598-613): disp2 = per column of image 2 the
+    // disparity of the cheapest winner pointing at it, kept in LDS for the row
+    const bool lrc = DIR == DIR_RIGHT && a.disp12 < 100000;
+    int16_t* d2p = sOut + 4 * a.w1 + wv * a.W;
+    int16_t* d2c = sOut + 4 * a.w1 + 4 * a.W + wv * a.W;
+    if (lrc)
+        for (int x = lane; x < a.W; x += 64) { d2p[x] = invalid; d2c[x] = (int16_t)SG_MAX_COST; }   // :449-453
 
     // one step of formula 13 at scanline position t with the operands c (block cost) and s (S so far)
     auto step = [&](int t, const int (&c)[DPL], const int (&s)[DPL]) {
@@ -296,6 +305,10 @@ __global__ void __launch_bounds__(256) sgbm_path_kernel(PathArgs a)
                 int res = invalid;
                 if (minS < SG_MAX_COST && !any_reject) {
                     int d = best < a.D ? best : 0;
+                    if (lrc && lane == 0) {                   // :549-554 (x runs from the right: sequential in this wave)
+                        const int x2 = (a.w1 - 1 - t) + a.minX1 - d - a.minD;
+                        if (d2c[x2] > minS) { d2c[x2] = (int16_t)minS; d2p[x2] = (int16_t)(d + a.minD); }
+                    }
                     const int dm = d > 0 ? d - 1 : 0, dp = d < a.D - 1 ? d + 1 : d;
                     const int sm = sS[wv][dm], s0 = sS[wv][d], sp = sS[wv][dp];
                     if (0 < d && d < a.D - 1) {                // stereo_binary_sgbm.cpp:584-591
@@ -345,7 +358,19 @@ __global__ void __launch_bounds__(256) sgbm_path_kernel(PathArgs a)
 
     if (DIR == DIR_RIGHT) {                                   // the scanline's results, coalesced
         int16_t* out = a.out + (ptrdiff_t)blockIdx.y * a.out_pair + (ptrdiff_t)line * a.out_stride + a.minX1;
-        for (int x = lane; x < a.w1; x += 64) out[x] = myOut[x];
+        const int maxdiff = a.disp12 > 0 ? a.disp12 : 1;      // :141
+        for (int x1 = lane; x1 < a.w1; x1 += 64) {
+            int d1 = myOut[x1];
+            if (lrc && d1 != invalid) {                       // :598-613: both roundings must disagree to invalidate
+                const int x = x1 + a.minX1;
+                const int dlo = d1 >> SG_DISP_SHIFT, dhi = (d1 + SG_DISP_SCALE - 1) >> SG_DISP_SHIFT;
+                const int xlo = x - dlo, xhi = x - dhi;
+                if (0 <= xlo && xlo < a.W && d2p[xlo] >= a.minD && abs(d2p[xlo] - dlo) > maxdiff &&
+                    0 <= xhi && xhi < a.W && d2p[xhi] >= a.minD && abs(d2p[xhi] - dhi) > maxdiff)
+                    d1 = invalid;
+            }
+            out[x1] = (int16_t)d1;
+        }
     }
 }
 
@@ -425,7 +450,8 @@ hipError_t launch_paths(const PathArgs& a0, int mode, int n, hipStream_t st)
         const int nlines = a.dy == 0 ? a.H : (a.dx == 0 ? a.w1 : a.w1 + a.H - 1);
         hipLaunchKernelGGL((sgbm_path_kernel<DPL, DIR_ADD>), dim3((nlines + 3) / 4, n), dim3(256), 0, st, a);
     }
-    const size_t lds_out = (size_t)a.w1 * 4 * sizeof(int16_t);
+    const size_t lds_out = ((size_t)a.w1 + (a.disp12 < 100000 ? 2 * (size_t)a.W : 0)) * 4 * sizeof(int16_t);
+    if (lds_out > 150 * 1024) return hipErrorInvalidValue;
     if (lds_out > 48 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(sgbm_path_kernel<DPL, DIR_RIGHT>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_out);
@@ -443,7 +469,8 @@ hipError_t launch_paths(const PathArgs& a0, int mode, int n, hipStream_t st)
 struct adf_sgbm {
     int device = 0;
     int min_disp = 0, num_disp = 16, block = 3;
-    int P1 = 0, P2 = 0, cap = 0, uniq = 10, mode = ADF_SGBM_MODE_SGBM;   // cv::StereoSGBM::create's defaults
+    int P1 = 0, P2 = 0, cap = 0, uniq = 0, mode = ADF_SGBM_MODE_SGBM;    // cv::StereoSGBM::create's defaults
+    int disp12 = 0;                                                        // ... incl. disp12MaxDiff = 0, which the algorithm reads as 1 (check ON)
     void* ws = nullptr; size_t ws_bytes = 0;
     void* stage = nullptr; size_t stage_bytes = 0;
     size_t ws_limit = (size_t)64 << 30;
@@ -499,6 +526,20 @@ extern "C" int adf_sgbm_get_params(const adf_sgbm_t* h, int* min_disparity, int*
     return ADF_OK;
 }
 
+extern "C" int adf_sgbm_set_disp12_max_diff(adf_sgbm_t* h, int v)
+{
+    if (!h) return sg_fail(ADF_EBADARG, "handle is NULL");
+    h->disp12 = v;
+    return ADF_OK;
+}
+
+extern "C" int adf_sgbm_get_disp12_max_diff(const adf_sgbm_t* h, int* v)
+{
+    if (!h) return sg_fail(ADF_EBADARG, "handle is NULL");
+    if (v) *v = h->disp12;
+    return ADF_OK;
+}
+
 extern "C" int adf_sgbm_get_device(const adf_sgbm_t* h, int* device)
 {
     if (!h) return sg_fail(ADF_EBADARG, "handle is NULL");
@@ -522,6 +563,8 @@ static int sgbm_check(const adf_sgbm* h, int n, const void* l, const void* r, co
     if (bs % 2 == 0 || bs > 11) return sg_fail(ADF_EBADARG, "blockSize must be odd and at most 11");
     if (h->min_disp < -2047 || h->min_disp + h->num_disp > 2047) return sg_fail(ADF_EBADARG, "disparity range does not fit CV_16S with 4 fractional bits");
     if (h->P1 < 0 || h->P2 < 0 || h->P1 > 8000 || h->P2 > 16000) return sg_fail(ADF_EBADARG, "P1 / P2 out of range");
+    if (h->disp12 < 100000 && (size_t)(W + 2 * (size_t)W) * 8 > 150 * 1024)
+        return sg_fail(ADF_ESIZE, "the matcher's own left-right check (disp12MaxDiff) supports images up to 6400 columns");
     return ADF_OK;
 }
 
@@ -586,7 +629,7 @@ extern "C" int adf_sgbm_compute_device(adf_sgbm_t* h, int n_pairs,
             const dim3 cgrid(w1, (H + rpb - 1) / rpb, n), cblock((D + 63) / 64 * 64);
             hipError_t e = cn == 1 ? launch_cost<1>(ca, bs, cgrid, cblock, st) : launch_cost<3>(ca, bs, cgrid, cblock, st);
             if (e != hipSuccess) return sg_fail(ADF_EHIP, hipGetErrorString(e));
-            PathArgs pa{Cv, Sv, volp, W, H, D, minD, minX1, w1, P1, P2, ur, raw, (ptrdiff_t)W, (ptrdiff_t)raw_el, 0, 0};
+            PathArgs pa{Cv, Sv, volp, W, H, D, minD, minX1, w1, P1, P2, ur, raw, (ptrdiff_t)W, (ptrdiff_t)raw_el, 0, 0, h->disp12};
             e = D <= 64 ? launch_paths<1>(pa, h->mode, n, st) : D <= 128 ? launch_paths<2>(pa, h->mode, n, st)
               : D <= 256 ? launch_paths<4>(pa, h->mode, n, st) : launch_paths<8>(pa, h->mode, n, st);
             if (e != hipSuccess) return sg_fail(ADF_EHIP, hipGetErrorString(e));

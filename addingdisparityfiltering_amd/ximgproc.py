@@ -425,7 +425,7 @@ class StereoSGBM(StereoMatcher):
     def __init__(self, minDisparity=0, numDisparities=16, blockSize=3, P1=0, P2=0, mode=0, preFilterCap=0):
         super().__init__(minDisparity, numDisparities, blockSize)
         self.P1, self.P2, self.mode, self.preFilterCap = P1, P2, mode, preFilterCap
-        self.disp12MaxDiff = 0          # cv::StereoSGBM::create's default (the filter factory raises it to 1000000)
+        self.disp12MaxDiff, self.uniquenessRatio = 0, 0     # cv::StereoSGBM::create's defaults (the filter factory raises disp12MaxDiff to 1000000)
         self._h = None
 
     @staticmethod
@@ -456,13 +456,10 @@ class StereoSGBM(StereoMatcher):
         """StereoMatcher::compute: CV_8UC1 / CV_8UC3 views (H,W[,3]) or a batch (N,H,W[,3]) -> CV_16SC1 disparity*16,
         invalid pixels (minDisparity-1)*16.  torch CUDA tensors are matched where they are, asynchronously on torch's
         current stream; numpy arrays take the host entry point.  MODE_SGBM_3WAY (3 paths, the sample's), MODE_SGBM (5)
-        and MODE_HH (8); the matcher's own left-right check and speckle filter are not built (the filter factory
-        switches both off, DF.cpp:389-390)."""
+        and MODE_HH (8), the matcher's own left-right check (disp12MaxDiff; create's default 0 reads as 1, the filter
+        factory switches it off with 1000000, DF.cpp:389); the speckle filter is not built (DF.cpp:390 sets it to 0)."""
         if self.mode not in (StereoSGBM.MODE_SGBM, StereoSGBM.MODE_HH, StereoSGBM.MODE_SGBM_3WAY):
             raise AdfError(_lib.ADF_EBADARG, "mode must be StereoSGBM.MODE_SGBM, MODE_HH or MODE_SGBM_3WAY")
-        if self.disp12MaxDiff < 1000000:
-            raise AdfError(_lib.ADF_EBADARG, "disp12MaxDiff (left-right check inside the matcher) is not implemented: "
-                                             "createDisparityWLSFilter sets it to 1000000")
         if self.speckleWindowSize > 0:
             raise AdfError(_lib.ADF_EBADARG, "speckle filtering is not implemented")
         nd = len(left.shape)
@@ -488,6 +485,7 @@ class StereoSGBM(StereoMatcher):
         _lib.check(lib.adf_sgbm_set_params(self._h, int(self.minDisparity), int(self.numDisparities), int(self.blockSize),
                                            int(self.P1), int(self.P2), int(self.preFilterCap), int(self.uniquenessRatio),
                                            int(self.mode)))
+        _lib.check(lib.adf_sgbm_set_disp12_max_diff(self._h, int(self.disp12MaxDiff)))
         args = [self._h, L.n, C.c_void_p(L.ptr), L.stride, L.pair_stride, C.c_void_p(R.ptr), R.stride, R.pair_stride,
                 L.c, L.w, L.h, C.c_void_p(D.ptr), D.stride, D.pair_stride]
         if L.device:

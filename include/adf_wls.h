@@ -297,19 +297,24 @@ int adf_bm_compute_host(adf_bm_t* h, int n_pairs,
  * [max(minDisparity+numDisparities,0), W+min(minDisparity,0)).  The class itself lives in OpenCV's calib3d (outside
  * the reference tree: parity unpinned); results are bit-exact against oracle/adf_oracle_sgbm.c and anchored on the
  * reference's own semi-global test (modules/stereo/test/test_block_matching.cpp:157-238).  Not implemented, and not
- * reachable from the filter (its factories switch them off): the matcher's own left-right check (disp12MaxDiff) and
- * speckle filter.  Limits: numDisparities <= 512, blockSize odd <= 11. */
+ * reachable from the filter (its factories switch it off): the speckle filter.  Limits: numDisparities <= 512,
+ * blockSize odd <= 11. */
 #define ADF_SGBM_MODE_SGBM 0
 #define ADF_SGBM_MODE_HH 1
 #define ADF_SGBM_MODE_3WAY 2 /* StereoSGBM::MODE_SGBM_3WAY */
 typedef struct adf_sgbm adf_sgbm_t; /* cv::Ptr<StereoSGBM> */
 /* StereoSGBM::create(minDisparity, numDisparities, blockSize); the other parameters start at its defaults
- * (P1 = P2 = 0, preFilterCap 0, uniquenessRatio 10, mode MODE_SGBM). */
+ * (P1 = P2 = 0, preFilterCap 0, uniquenessRatio 0, disp12MaxDiff 0, mode MODE_SGBM). */
 int adf_sgbm_create(adf_sgbm_t** out, int min_disparity, int num_disparities, int block_size);
 void adf_sgbm_destroy(adf_sgbm_t* h);
 int adf_sgbm_get_device(const adf_sgbm_t* h, int* device);
 int adf_sgbm_set_params(adf_sgbm_t* h, int min_disparity, int num_disparities, int block_size, int P1, int P2,
                         int prefilter_cap, int uniqueness_ratio, int mode);
+/* StereoSGBM::setDisp12MaxDiff: the matcher's own left-right check (stereo_binary_sgbm.cpp:548-556, 598-613 is the in-tree
+ * statement).  cv::StereoSGBM::create's default 0 is read as 1 by the algorithm (check ON, :141); the filter factory sets
+ * 1000000 (disparity_filters.cpp:389, 444), which switches it off. */
+int adf_sgbm_set_disp12_max_diff(adf_sgbm_t* h, int disp12_max_diff);
+int adf_sgbm_get_disp12_max_diff(const adf_sgbm_t* h, int* disp12_max_diff);
 int adf_sgbm_get_params(const adf_sgbm_t* h, int* min_disparity, int* num_disparities, int* block_size, int* P1, int* P2,
                         int* prefilter_cap, int* uniqueness_ratio, int* mode);
 /* StereoMatcher::compute(left, right, disparity) on n_pairs equally sized CV_8UC1 / CV_8UC3 pairs (`channels`);

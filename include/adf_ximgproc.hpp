@@ -318,7 +318,7 @@ inline Ptr<StereoBM> createRightMatcher(const Ptr<StereoBM>& matcher_left)
 // ---------------------------------------------------------------------------------------------------------
 class StereoSGBM {
     adf_sgbm_t* h_ = nullptr;
-    int min_disp_, num_disp_, block_, P1_ = 0, P2_ = 0, cap_ = 0, uniq_ = 10, mode_ = MODE_SGBM;   // cv::StereoSGBM::create's defaults
+    int min_disp_, num_disp_, block_, P1_ = 0, P2_ = 0, cap_ = 0, uniq_ = 0, mode_ = MODE_SGBM;    // cv::StereoSGBM::create's defaults
     int disp12_ = 0, speckle_window_ = 0;
 public:
     enum { MODE_SGBM = ADF_SGBM_MODE_SGBM, MODE_HH = ADF_SGBM_MODE_HH, MODE_SGBM_3WAY = ADF_SGBM_MODE_3WAY };
@@ -351,9 +351,10 @@ public:
             throw Exception(ADF_EBADARG, "Both input images must have CV_8UC1 or CV_8UC3");
         if (left.rows != right.rows || left.cols != right.cols)
             throw Exception(ADF_ESIZE, "All the images must have the same size");
-        if (disp12_ < 1000000 || speckle_window_ > 0)                            // the filter factory switches both off (DF.cpp:389-390)
-            throw Exception(ADF_EBADARG, "the matcher's own left-right check and speckle filter are not implemented");
+        if (speckle_window_ > 0)                                                 // the filter factory switches it off (DF.cpp:390)
+            throw Exception(ADF_EBADARG, "the matcher's speckle filter is not implemented");
         check(adf_sgbm_set_params(h_, min_disp_, num_disp_, block_, P1_, P2_, cap_, uniq_, mode_));
+        check(adf_sgbm_set_disp12_max_diff(h_, disp12_));
         Mat out;
         mat_create(out, left.rows, left.cols, D16S, 1);
         check(adf_sgbm_compute_host(h_, 1, left.data, mat_step(left), 0, right.data, mat_step(right), 0, mat_channels(left),

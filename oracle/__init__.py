@@ -42,6 +42,7 @@ class SGBMParams(C.Structure):
         ("prefilter_cap", C.c_int),
         ("uniqueness_ratio", C.c_int),
         ("mode", C.c_int),
+        ("disp12_max_diff", C.c_int),
     ]
 
 
@@ -325,8 +326,9 @@ def _sgbm_images(img1, img2):
 
 
 def sgbm_params(num_disparities, block_size, min_disparity=0, P1=0, P2=0, prefilter_cap=0, uniqueness_ratio=0,
-                mode=SGBM_MODE_3WAY):
-    return SGBMParams(min_disparity, num_disparities, block_size, P1, P2, prefilter_cap, uniqueness_ratio, mode)
+                mode=SGBM_MODE_3WAY, disp12_max_diff=1000000):
+    return SGBMParams(min_disparity, num_disparities, block_size, P1, P2, prefilter_cap, uniqueness_ratio, mode,
+                      disp12_max_diff)
 
 
 def sgbm_signals(img, prefilter_cap):
@@ -351,10 +353,11 @@ def sgbm_block_costs(img1, img2, prm):
 
 
 def sgbm_compute(img1, img2, num_disparities, block_size, min_disparity=0, P1=0, P2=0, prefilter_cap=0,
-                 uniqueness_ratio=0, mode=SGBM_MODE_3WAY, want_raw=False):
+                 uniqueness_ratio=0, mode=SGBM_MODE_3WAY, want_raw=False, disp12_max_diff=1000000):
     """Semi-global matcher restated from the published algorithm (adf_oracle_sgbm.c; parity unpinned)."""
     a, b, cn, W, H = _sgbm_images(img1, img2)
-    prm = sgbm_params(num_disparities, block_size, min_disparity, P1, P2, prefilter_cap, uniqueness_ratio, mode)
+    prm = sgbm_params(num_disparities, block_size, min_disparity, P1, P2, prefilter_cap, uniqueness_ratio, mode,
+                      disp12_max_diff)
     out = np.empty((H, W), np.int16)
     raw = np.empty((H, W), np.int16) if want_raw else None
     rc = lib().adf_oracle_sgbm_compute(C.byref(prm), _p(a), a.strides[0], _p(b), b.strides[0], cn, W, H, _p(out), W,

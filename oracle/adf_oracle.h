@@ -170,6 +170,7 @@ typedef struct adf_oracle_sgbm_params {
     int prefilter_cap;      /* sample: 63 */
     int uniqueness_ratio;   /* forced to 0 by the filter factory (disparity_filters.cpp:406,436); < 0 -> 10 */
     int mode;               /* ADF_SGBM_MODE_3WAY (3 paths), ADF_SGBM_MODE_SGBM (5), ADF_SGBM_MODE_HH (8) */
+    int disp12_max_diff;    /* the matcher's own left-right check; <= 0 -> 1; the filter factory sets 1000000 (off) */
 } adf_oracle_sgbm_params;
 /* (value, min, max over the half-sample neighbours) of every signal of every pixel: rec[H][W][2cn][3] */
 void adf_oracle_sgbm_signals(const uint8_t* img, ptrdiff_t stride, int cn, int W, int H, int prefilter_cap, uint8_t* rec);

@@ -29,8 +29,9 @@
  *      d + minDisparity*16 (:596); pixels outside [minX1, maxX1) and rejected ones hold (minDisparity-1)*16
  *      (:449-453, INVALID_DISP_SCALED :156);
  *   6. a 3x3 median over the CV_16S map (StereoSGBM::compute post-filter), border replicated.
- * Deliberately NOT restated (not reachable from the filter: the factories force disp12MaxDiff = 1000000 and
- * speckleWindowSize = 0, disparity_filters.cpp:389-390,444-445): the left-right consistency check (:598-613) and the
+ * The matcher's own left-right check (disp12MaxDiff, :548-556, 598-613) is restated too, so that cv::StereoSGBM::create's
+ * defaults run; the filter factories switch it off (disp12MaxDiff = 1000000, disparity_filters.cpp:389, 444).
+ * Deliberately NOT restated (not reachable from the filter: speckleWindowSize = 0, disparity_filters.cpp:390, 445): the
  * speckle filter.  OpenCV's 3-way code also cuts the image into horizontal stripes for its threads and restarts the
  * vertical path in each (results depend on the stripe count); this restatement is the one-stripe case.
  * Matchable columns: minX1 = max(maxD, 0), maxX1 = W + min(minD, 0) as in calib3d (the in-tree census variant has
@@ -193,6 +194,47 @@ static inline int path_step(const int16_t* Cp, const int16_t* Lprev, int minprev
     return mn;
 }
 
+/* Winner, uniqueness test, sub-pixel fit and the matcher's own left-right check for ONE image row whose summed
+ * costs S[x1][d] are complete (stereo_binary_sgbm.cpp:449-453, 519-613): x runs from the right (:456); the reverse
+ * map disp2 keeps, per column of image 2, the disparity of the cheapest winner pointing at it (:548-556); a pixel
+ * is invalidated when BOTH roundings of its disparity disagree with disp2 by more than disp12MaxDiff (:598-613).
+ * disp12 <= 0 means 1 (:141); the filter factory sets 1000000, which switches the check off. */
+static void select_row(const int16_t* S, int w1, int D, int W, int minD, int minX1, int ur, int disp12, int16_t* out,
+                       int16_t* disp2ptr, int16_t* disp2cost)
+{
+    const int invalid = (minD - 1) * DISP_SCALE;
+    const int maxdiff = disp12 > 0 ? disp12 : 1;
+    for (int x = 0; x < W; x++) { disp2ptr[x] = (int16_t)invalid; disp2cost[x] = SGBM_MAX_COST; }     /* :449-453 */
+    for (int x = w1 - 1; x >= 0; x--) {
+        const int16_t* Sp = S + (size_t)x * D;
+        int minS = SGBM_MAX_COST, best = -1;
+        for (int d = 0; d < D; d++) if (Sp[d] < minS) { minS = Sp[d]; best = d; }                     /* :524-528 */
+        if (best < 0) continue;                                          /* every S saturated: stays invalid */
+        int d;
+        for (d = 0; d < D; d++)                                          /* :543-547 */
+            if (Sp[d] * (100 - ur) < minS * 100 && abs(best - d) > 1) break;
+        if (d < D) continue;
+        d = best;
+        const int x2 = x + minX1 - d - minD;                             /* :549-554 */
+        if (disp2cost[x2] > minS) { disp2cost[x2] = (int16_t)minS; disp2ptr[x2] = (int16_t)(d + minD); }
+        if (0 < d && d < D - 1) {                                        /* :584-591 */
+            const int denom2 = imax2(Sp[d - 1] + Sp[d + 1] - 2 * Sp[d], 1);
+            d = d * DISP_SCALE + ((Sp[d - 1] - Sp[d + 1]) * DISP_SCALE + denom2) / (denom2 * 2);
+        } else
+            d *= DISP_SCALE;
+        out[x + minX1] = (int16_t)(d + minD * DISP_SCALE);               /* :596 */
+    }
+    for (int x = minX1; x < minX1 + w1; x++) {                           /* :598-613 */
+        const int d1 = out[x];
+        if (d1 == invalid) continue;
+        const int dlo = d1 >> DISP_SHIFT, dhi = (d1 + DISP_SCALE - 1) >> DISP_SHIFT;
+        const int xlo = x - dlo, xhi = x - dhi;
+        if (0 <= xlo && xlo < W && disp2ptr[xlo] >= minD && abs(disp2ptr[xlo] - dlo) > maxdiff &&
+            0 <= xhi && xhi < W && disp2ptr[xhi] >= minD && abs(disp2ptr[xhi] - dhi) > maxdiff)
+            out[x] = (int16_t)invalid;
+    }
+}
+
 /* Formula 13 along an arbitrary direction of travel (dx, dy), added into the volume S[y][x][d] (saturating):
  * the pixel before (x, y) on the path is (x - dx, y - dy); a path entering the matchable area starts from zeros
  * (the border cells of the Lr / minLr buffers are cleared, stereo_binary_sgbm.cpp:191-194, 279-283).  MODE_SGBM sums
@@ -225,7 +267,7 @@ static void add_path(const int16_t* C, int16_t* S, int H, int w1, int D, int dx,
 }
 
 /* MODE_SGBM / MODE_HH: whole volumes in memory (tests and small images). */
-static void sgbm_multipath(const sgbm_geom* g, int mode, int P1, int P2, int ur, int minD, int16_t* tmp)
+static void sgbm_multipath(const sgbm_geom* g, int mode, int P1, int P2, int ur, int disp12, int minD, int16_t* tmp)
 {
     const int D = g->D, w1 = g->width1, H = g->H, W = g->W;
     const size_t rowsz = (size_t)w1 * D, K = (size_t)(2 * g->SH2 + 1);
@@ -250,26 +292,11 @@ static void sgbm_multipath(const sgbm_geom* g, int mode, int P1, int P2, int ur,
         if (mode == ADF_SGBM_MODE_3WAY_GENERIC && (k & 1)) continue;   /* test hook: left, up, right only */
         add_path(C, S, H, w1, D, dirs[k][0], dirs[k][1], P1, P2);
     }
-    for (int y = 0; y < H; y++) {
-        int16_t* out = tmp + (size_t)y * W;
-        for (int x = 0; x < w1; x++) {
-            const int16_t* Sp = S + ((size_t)y * w1 + x) * D;
-            int minS = SGBM_MAX_COST, best = -1;
-            for (int d = 0; d < D; d++) if (Sp[d] < minS) { minS = Sp[d]; best = d; }   /* :519-528, 536-546 */
-            if (best < 0) continue;
-            int d;
-            for (d = 0; d < D; d++)
-                if (Sp[d] * (100 - ur) < minS * 100 && abs(best - d) > 1) break;
-            if (d < D) continue;
-            d = best;
-            if (0 < d && d < D - 1) {
-                const int denom2 = imax2(Sp[d - 1] + Sp[d + 1] - 2 * Sp[d], 1);
-                d = d * DISP_SCALE + ((Sp[d - 1] - Sp[d + 1]) * DISP_SCALE + denom2) / (denom2 * 2);
-            } else
-                d *= DISP_SCALE;
-            out[x + g->minX1] = (int16_t)(d + minD * DISP_SCALE);
-        }
-    }
+    int16_t* d2p = (int16_t*)malloc(sizeof(int16_t) * (size_t)W);
+    int16_t* d2c = (int16_t*)malloc(sizeof(int16_t) * (size_t)W);
+    for (int y = 0; y < H; y++)
+        select_row(S + (size_t)y * rowsz, w1, D, W, minD, g->minX1, ur, disp12, tmp + (size_t)y * W, d2p, d2c);
+    free(d2p); free(d2c);
     free(pix); free(hs); free(C); free(S);
 }
 
@@ -312,7 +339,7 @@ int adf_oracle_sgbm_compute(const adf_oracle_sgbm_params* p, const uint8_t* img1
         adf_oracle_sgbm_signals(img1, s1, cn, W, H, p->prefilter_cap, r1);
         adf_oracle_sgbm_signals(img2, s2, cn, W, H, p->prefilter_cap, r2);
         g.r1 = r1; g.r2 = r2;
-        sgbm_multipath(&g, p->mode, P1, P2, ur, minD, tmp);
+        sgbm_multipath(&g, p->mode, P1, P2, ur, p->disp12_max_diff, minD, tmp);
         free(r1); free(r2);
     } else if (w1 > 0) {
         uint8_t* r1 = (uint8_t*)malloc((size_t)W * H * 6 * cn);
@@ -330,6 +357,8 @@ int adf_oracle_sgbm_compute(const adf_oracle_sgbm_params* p, const uint8_t* img1
         int16_t* S = (int16_t*)malloc(sizeof(int16_t) * rowsz);
         int16_t* Ltop = (int16_t*)calloc((size_t)w1 * (D + 2), sizeof(int16_t));   /* zero start, :191-194 */
         int* minTop = (int*)calloc((size_t)w1, sizeof(int));
+        int16_t* d2p = (int16_t*)malloc(sizeof(int16_t) * (size_t)W);
+        int16_t* d2c = (int16_t*)malloc(sizeof(int16_t) * (size_t)W);
         int16_t* La = (int16_t*)malloc(sizeof(int16_t) * (size_t)(D + 2));
         int16_t* Lb = (int16_t*)malloc(sizeof(int16_t) * (size_t)(D + 2));
         int16_t* Lt = (int16_t*)malloc(sizeof(int16_t) * (size_t)(D + 2));
@@ -368,25 +397,11 @@ int adf_oracle_sgbm_compute(const adf_oracle_sgbm_params* p, const uint8_t* img1
                 int16_t* Sp = S + (size_t)x * D;
                 minRight = path_step(Cp, La, minRight, Lb, D, P1, P2);
                 { int16_t* t = La; La = Lb; Lb = t; }
-                int minS = SGBM_MAX_COST, best = -1;
-                for (int d = 0; d < D; d++) {
-                    const int sv = Sp[d] = sat_s16((int)Sp[d] + (int)La[d + 1]);
-                    if (sv < minS) { minS = sv; best = d; }                     /* :524-528 */
-                }
-                if (best < 0) continue;                                          /* every S saturated: stays invalid */
-                int d;
-                for (d = 0; d < D; d++)                                          /* :543-547 */
-                    if (Sp[d] * (100 - ur) < minS * 100 && abs(best - d) > 1) break;
-                if (d < D) continue;
-                d = best;
-                if (0 < d && d < D - 1) {                                        /* :584-591 */
-                    const int denom2 = imax2(Sp[d - 1] + Sp[d + 1] - 2 * Sp[d], 1);
-                    d = d * DISP_SCALE + ((Sp[d - 1] - Sp[d + 1]) * DISP_SCALE + denom2) / (denom2 * 2);
-                } else
-                    d *= DISP_SCALE;
-                out[x + g.minX1] = (int16_t)(d + minD * DISP_SCALE);             /* :596 */
+                for (int d = 0; d < D; d++) Sp[d] = sat_s16((int)Sp[d] + (int)La[d + 1]);
             }
+            select_row(S, w1, D, W, minD, g.minX1, ur, p->disp12_max_diff, out, d2p, d2c);
         }
+        free(d2p); free(d2c);
         free(pix); free(ring); free(ring_row); free(C); free(S); free(Ltop); free(minTop); free(La); free(Lb); free(Lt);
         free(r1); free(r2);
     }

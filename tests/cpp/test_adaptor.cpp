@@ -146,7 +146,7 @@ int main()
         sl->compute(left, right, sdl);
         sr->compute(right, left, sdr);
         wls2->filter(sdl, left, sout, sdr);
-        adf_oracle_sgbm_params sp = {0, nd, bs, 24 * bs * bs, 96 * bs * bs, 63, 0, ADF_SGBM_MODE_3WAY};
+        adf_oracle_sgbm_params sp = {0, nd, bs, 24 * bs * bs, 96 * bs * bs, 63, 0, ADF_SGBM_MODE_3WAY, 1000000};
         EXPECT(adf_oracle_sgbm_compute(&sp, left.data, (ptrdiff_t)left.step, right.data, (ptrdiff_t)right.step, 1, W, H, edl.ptr<int16_t>(), W, nullptr) == 0);
         sp.min_disparity = -nd + 1;
         EXPECT(adf_oracle_sgbm_compute(&sp, right.data, (ptrdiff_t)right.step, left.data, (ptrdiff_t)left.step, 1, W, H, edr.ptr<int16_t>(), W, nullptr) == 0);
@@ -160,9 +160,16 @@ int main()
                                      exp.ptr<int16_t>(), (ptrdiff_t)exp.step, nullptr) == 0);
         EXPECT(std::memcmp(sout.data, exp.data, (size_t)H * exp.step) == 0);
         threw = false;
-        try { Ptr<StereoSGBM> q = StereoSGBM::create(0, 16, 3); q->compute(left, right, sdl); }
-        catch (const Exception&) { threw = true; }                             // create's default disp12MaxDiff = 0: the matcher's own left-right check is not built
+        try { Ptr<StereoSGBM> q = StereoSGBM::create(0, 16, 3); q->setSpeckleWindowSize(100); q->compute(left, right, sdl); }
+        catch (const Exception&) { threw = true; }                             // the speckle filter is not built
         EXPECT(threw);
+        {   // cv::StereoSGBM::create's defaults run: MODE_SGBM, the matcher's own left-right check on (disp12MaxDiff 0 -> 1)
+            Ptr<StereoSGBM> q = StereoSGBM::create(0, nd, bs);
+            q->compute(left, right, sdl);
+            adf_oracle_sgbm_params dp = {0, nd, bs, 0, 0, 0, 0, ADF_SGBM_MODE_SGBM, 0};
+            EXPECT(adf_oracle_sgbm_compute(&dp, left.data, (ptrdiff_t)left.step, right.data, (ptrdiff_t)right.step, 1, W, H, edl.ptr<int16_t>(), W, nullptr) == 0);
+            EXPECT(std::memcmp(sdl.data, edl.data, (size_t)H * edl.step) == 0);
+        }
     }
     {   // error behaviour: exceptions like CV_Assert / CV_Error
         Mat view(48, 64, D8U, 3), dl(48, 64, D16S, 1), out;

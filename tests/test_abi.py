@@ -81,8 +81,9 @@ def test_matcher_factories_host_logic():
     with pytest.raises(adf.AdfError):                       # unknown mode
         right.compute(np.zeros((8, 8), np.uint8), np.zeros((8, 8), np.uint8))
     fresh = adf.StereoSGBM.create(0, 16, 3)
-    fresh.setMode(adf.StereoSGBM.MODE_SGBM_3WAY)
-    with pytest.raises(adf.AdfError):                       # ... and not the matcher's own left-right check (create's default)
+    assert (fresh.getMode(), fresh.getDisp12MaxDiff(), fresh.getUniquenessRatio()) == (0, 0, 0)   # cv::StereoSGBM::create's defaults
+    fresh.setSpeckleWindowSize(50)
+    with pytest.raises(adf.AdfError):                       # the speckle filter is not built
         fresh.compute(np.zeros((8, 8), np.uint8), np.zeros((8, 8), np.uint8))
 
 

@@ -124,7 +124,7 @@ def test_matcher_errors(adf):
     m = _sgbm(adf, 16, 3); m.setMode(5)
     with pytest.raises(adf.AdfError):
         m.compute(a, b)
-    m = _sgbm(adf, 16, 3); m.setDisp12MaxDiff(1)
+    m = _sgbm(adf, 16, 3); m.setSpeckleWindowSize(100)
     with pytest.raises(adf.AdfError):
         m.compute(a, b)
     with pytest.raises(adf.AdfError):
@@ -171,3 +171,27 @@ def test_modes_on_the_reference_fixture(adf, oracle):
         got = _sgbm(adf, 16, 3, 0, 216, 864, 63, 0, mode).compute(left, right)
         assert np.array_equal(got, oracle.sgbm_compute(left, right, 16, 3, 0, 216, 864, 63, 0, mode=mode))
         assert ref_error_level(gt, got) <= 10.0
+
+
+@pytest.mark.parametrize("mode", [0, 1, 2])
+@pytest.mark.parametrize("md,disp12,nd", [(0, 0, 16), (0, 1, 32), (0, 3, 16), (-15, 1, 16), (4, 2, 16), (0, 1, 160)])
+def test_matchers_own_left_right_check(adf, oracle, mode, md, disp12, nd):
+    """disp12MaxDiff inside the matcher: cv::StereoSGBM::create's default leaves it on (0 -> 1)."""
+    rng = np.random.default_rng(400 + mode + nd)
+    H, W = 30, nd + 110
+    base = rng.integers(0, 256, (H, W + 60), dtype=np.uint8)
+    a = np.ascontiguousarray(base[:, 20:20 + W])
+    b = np.ascontiguousarray(base[:, 23:23 + W]).copy()
+    b[:, W // 2:] = base[:, 20 + 9 + W // 2:20 + 9 + W]              # right half at a larger disparity: occlusions
+    m = _sgbm(adf, nd, 3, md, 72, 288, 63, 0, mode); m.setDisp12MaxDiff(disp12)
+    got = m.compute(a, b)
+    exp = oracle.sgbm_compute(a, b, nd, 3, md, 72, 288, 63, 0, mode=mode, disp12_max_diff=disp12)
+    assert np.array_equal(got, exp)
+
+
+def test_create_defaults_run(adf, oracle):
+    """StereoSGBM.create(minDisparity, numDisparities, blockSize) with everything else at cv::StereoSGBM's defaults:
+    MODE_SGBM, P1 = P2 = 0 (-> 2 / 5), preFilterCap 0 (-> 15), uniquenessRatio 0, disp12MaxDiff 0 (-> 1, check on)."""
+    a, b = _pair(12, 40, 140, shift=7)
+    m = adf.StereoSGBM.create(0, 32, 5)
+    assert np.array_equal(m.compute(a, b), oracle.sgbm_compute(a, b, 32, 5, 0, 0, 0, 0, 0, mode=0, disp12_max_diff=0))

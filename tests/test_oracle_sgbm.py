@@ -25,7 +25,7 @@ DIRS = {2: [(1, 0), (0, 1), (-1, 0)],                                           
         1: [(1, 0), (1, 1), (0, 1), (-1, 1), (-1, 0), (-1, -1), (0, -1), (1, -1)]}          # MODE_HH
 
 
-def naive_sgbm(img1, img2, nd, bs, md=0, P1=0, P2=0, cap=0, ur=0, mode=2):
+def naive_sgbm(img1, img2, nd, bs, md=0, P1=0, P2=0, cap=0, ur=0, mode=2, disp12=1000000):
     """Independent direct statement (numpy, whole cost volume in memory) of the definition in adf_oracle_sgbm.c."""
     a = img1.astype(np.int64); b = img2.astype(np.int64)
     if a.ndim == 2:
@@ -89,8 +89,10 @@ def naive_sgbm(img1, img2, nd, bs, md=0, P1=0, P2=0, cap=0, ur=0, mode=2):
                 else:
                     L[y, x], M[y, x] = step(Cv[y, x], np.zeros(nd, np.int64), 0)
         S = np.clip(S + L, -32768, SHRT_MAX)
+    maxdiff = disp12 if disp12 > 0 else 1
     for y in range(H):
-        for x in range(w1):
+        d2p = np.full(W, (md - 1) * 16, np.int64); d2c = np.full(W, SHRT_MAX, np.int64)
+        for x in range(w1 - 1, -1, -1):                              # from the right (stereo_binary_sgbm.cpp:456)
             Sp = S[y, x]
             best = int(np.argmin(Sp)); ms = int(Sp[best])            # argmin: first minimum
             if ms >= SHRT_MAX:
@@ -98,6 +100,9 @@ def naive_sgbm(img1, img2, nd, bs, md=0, P1=0, P2=0, cap=0, ur=0, mode=2):
             if ur > 0 and any(Sp[d] * (100 - ur) < ms * 100 and abs(best - d) > 1 for d in range(nd)):
                 continue
             d = best
+            x2 = x + minx1 - d - md
+            if d2c[x2] > ms:
+                d2c[x2] = ms; d2p[x2] = d + md
             if 0 < d < nd - 1:
                 den = max(int(Sp[d - 1] + Sp[d + 1] - 2 * Sp[d]), 1)
                 num = int(Sp[d - 1] - Sp[d + 1]) * 16 + den
@@ -105,6 +110,15 @@ def naive_sgbm(img1, img2, nd, bs, md=0, P1=0, P2=0, cap=0, ur=0, mode=2):
             else:
                 d *= 16
             out[y, x + minx1] = d + md * 16
+        for x in range(minx1, maxx1):                                # the matcher's own left-right check (:598-613)
+            d1 = int(out[y, x])
+            if d1 == (md - 1) * 16:
+                continue
+            lo, hi = d1 >> 4, (d1 + 15) >> 4
+            xl, xh = x - lo, x - hi
+            if (0 <= xl < W and d2p[xl] >= md and abs(d2p[xl] - lo) > maxdiff and
+                    0 <= xh < W and d2p[xh] >= md and abs(d2p[xh] - hi) > maxdiff):
+                out[y, x] = (md - 1) * 16
     return out
 
 
@@ -186,3 +200,23 @@ def test_invalid_columns_and_range(oracle):
     assert (raw[:, :32] == -16).all() and (raw[:, 32:] >= 0).all() and (raw[:, 32:] <= 31 * 16).all()
     raw = oracle.sgbm_compute(b, a, 32, 3, -31, 72, 288, 63, want_raw=True)[1]      # createRightMatcher's range
     assert (raw[:, 90 - 31:] == -32 * 16).all() and (raw[:, 1:90 - 31] <= 0).all() and (raw[:, 0] == -32 * 16).all()
+
+
+@pytest.mark.parametrize("mode", [0, 1, 2])
+@pytest.mark.parametrize("md,disp12", [(0, 0), (0, 1), (0, 3), (-15, 1), (4, 2)])
+def test_matchers_own_left_right_check(oracle, mode, md, disp12):
+    """disp12MaxDiff (stereo_binary_sgbm.cpp:548-556, 598-613): cv::StereoSGBM::create's default (0 -> 1) leaves the
+    check ON; the filter factory switches it off with 1000000.  An occluding step makes it fire."""
+    rng = np.random.default_rng(40 + mode)
+    H, W = 14, 70
+    base = rng.integers(0, 256, (H, W + 40), dtype=np.uint8)
+    a = np.ascontiguousarray(base[:, 20:20 + W])
+    b = np.ascontiguousarray(base[:, 23:23 + W]).copy()
+    b[:, 30:] = base[:, 20 + 39:20 + 39 + W - 30]                    # right half at a larger disparity: occlusions
+    got, raw = oracle.sgbm_compute(a, b, 16, 3, md, 72, 288, 63, 0, mode=mode, want_raw=True, disp12_max_diff=disp12)
+    exp_raw = naive_sgbm(a, b, 16, 3, md, 72, 288, 63, 0, mode=mode, disp12=disp12)
+    assert np.array_equal(raw, exp_raw)
+    off = oracle.sgbm_compute(a, b, 16, 3, md, 72, 288, 63, 0, mode=mode, want_raw=True)[1]
+    if md == 0 and disp12 <= 1:
+        assert (raw != off).any()                                    # the check invalidates something
+    assert ((raw == off) | (raw == (md - 1) * 16)).all()             # ... and only ever invalidates
