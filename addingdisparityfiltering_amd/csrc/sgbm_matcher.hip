@@ -12,9 +12,10 @@
 //   sgbm_signals_kernel   per pixel and channel: clipped x-derivative + intensity, each with the extrema over its
 //                         half-sample neighbours, packed as 16-bit pairs (derivative | intensity) so that one packed
 //                         instruction serves both Birchfield-Tomasi terms
-//   sgbm_cost_kernel      block cost volume C[y][x][d] (int16): one workgroup = one matchable column x, one thread =
-//                         one disparity, walking down a band of rows with the horizontal window summed directly and
-//                         the vertical window as a running sum over a register ring (stereo_binary_sgbm.cpp:205-276)
+//   sgbm_cost_kernel      block cost volume C[y][x][d] (int16): lanes along x, 16 (8) disparities per wave, walking down
+//                         a band of rows; one pixel cost per lane, row and disparity, the horizontal window from the
+//                         neighbouring lanes by DPP, the vertical one as a running sum over a register ring
+//                         (stereo_binary_sgbm.cpp:205-276 is the same running-sum structure)
 //   sgbm_path_kernel      formula 13 along one direction, one wavefront per scanline, the D path costs of a pixel held
 //                         4 (2, 1, 8) per lane; d-1 / d+1 across lanes by whole-wave DPP shifts, min_k by a DPP
 //                         butterfly + 4 readlanes.  TOP writes the volume S, LEFT adds to it, RIGHT adds, picks the
@@ -104,24 +105,43 @@ __device__ __forceinline__ us2 bt_pair(const Rec& u, const Rec& v)
     return m >> sh;
 }
 
-template <int BS, int CN>
-__global__ void __launch_bounds__(512) sgbm_cost_kernel(CostArgs a)
+// Lanes run along x: lane = one matchable column (the first and last BS/2 lanes of a wave are halo and repeat the edge
+// column at the borders of the matchable area = the clamped window), wave = DD consecutive disparities of 64 - 2*(BS/2)
+// output columns, workgroup = 4 waves = 4*DD disparities of the same columns (their int16 results are one contiguous
+// piece per column).  Per row and disparity a lane evaluates ONE pixel cost (its own column of image 1 against column
+// x - d of image 2: consecutive lanes read consecutive records) and receives its neighbours' through whole-wave DPP
+// shifts; the vertical window is a running sum over a register ring with static slots (the row loop is unrolled by BS).
+template <int BS, int CN, int DD>
+__global__ void __launch_bounds__(256) sgbm_cost_kernel(CostArgs a)
 {
-    constexpr int R = BS / 2;
-    const int x1 = blockIdx.x, d = threadIdx.x;
-    if (d >= a.D) return;
-    const int y0 = blockIdx.y * a.rows_per_band;
+    constexpr int R = BS / 2, OUTW = 64 - 2 * R;
+    constexpr int TD = 4 * DD;                                // disparities of the workgroup: one contiguous piece per column
+    constexpr int TP = TD + 8;                                // LDS row pitch in int16 (16-byte aligned, staggers the banks)
+    __shared__ __align__(16) int16_t tile[2][64 * TP];        // the workgroup's results of one row, [column][disparity]
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int dbase = blockIdx.y * TD, d0 = dbase + wv * DD;
+    const bool wave_active = d0 < a.D;                        // (D is a multiple of 16, DD is 8 or 16: all or nothing per wave)
+    const int nbands = (a.H + a.rows_per_band - 1) / a.rows_per_band;
+    const int img = blockIdx.z / nbands, band = blockIdx.z % nbands;
+    const int y0 = band * a.rows_per_band;
     const int rows_out = min(a.rows_per_band, a.H - y0);
-    const uint32_t* rec1 = a.rec1 + (size_t)blockIdx.z * a.rec_pair;
-    const uint32_t* rec2 = a.rec2 + (size_t)blockIdx.z * a.rec_pair;
-    int16_t* C = a.C + (size_t)blockIdx.z * a.vol;
-    int ring[BS], csum = 0;
+    const int xt0 = blockIdx.x * OUTW;
+    const int x1 = xt0 + lane - R;
+    const int X = a.minX1 + min(max(x1, 0), a.w1 - 1);         // image column (window clamped inside the matchable area)
+    const uint32_t* rec1 = a.rec1 + (size_t)img * a.rec_pair;
+    const uint32_t* rec2 = a.rec2 + (size_t)img * a.rec_pair;
+    int16_t* C = a.C + (size_t)img * a.vol;
+    const int dl = wave_active ? d0 : dbase;                  // idle waves walk along (they share the barriers and the stores)
+    int ring[BS][DD], csum[DD];
 #pragma unroll
-    for (int k = 0; k < BS; k++) ring[k] = 0;
-    // columns of the horizontal window, clamped inside the matchable area (image columns)
-    int xu[BS];
+    for (int dd = 0; dd < DD; dd++) {
+        csum[dd] = 0;
 #pragma unroll
-    for (int j = 0; j < BS; j++) xu[j] = a.minX1 + min(max(x1 + j - R, 0), a.w1 - 1);
+        for (int k = 0; k < BS; k++) ring[k][dd] = 0;
+    }
+    // write-out: 16 bytes per thread, TD/8 threads per column => every store instruction covers whole contiguous pieces
+    constexpr int TPC = TD / 8;                               // threads per column
+    const int nd_blk = min(TD, a.D - dbase);                  // disparities this workgroup really has
     const int nsteps = rows_out + BS - 1;
     for (int n0 = 0; n0 < nsteps; n0 += BS) {
 #pragma unroll
@@ -129,24 +149,55 @@ __global__ void __launch_bounds__(512) sgbm_cost_kernel(CostArgs a)
             const int n = n0 + s;
             if (n < nsteps) {                                    // block-uniform
                 const int yy = min(max(y0 - R + n, 0), a.H - 1);
-                us2 acc = {0, 0};
+                const uint32_t* pu = rec1 + ((size_t)yy * a.W + X) * (CN * 3);
+                const uint32_t* pv = rec2 + ((size_t)yy * a.W + (X - (dl + a.minD))) * (CN * 3);
+                Rec u[CN];
 #pragma unroll
-                for (int j = 0; j < BS; j++) {
-                    const uint32_t* pu = rec1 + ((size_t)yy * a.W + xu[j]) * (CN * 3);                       // uniform
-                    const uint32_t* pv = rec2 + ((size_t)yy * a.W + (xu[j] - (d + a.minD))) * (CN * 3);      // per lane
+                for (int c = 0; c < CN; c++) u[c] = Rec{pu[c * 3], pu[c * 3 + 1], pu[c * 3 + 2]};
+                short res[DD];
+#pragma unroll
+                for (int dd = 0; dd < DD; dd++) {
+                    us2 acc = {0, 0};
 #pragma unroll
                     for (int c = 0; c < CN; c++) {
-                        const Rec u = {pu[c * 3], pu[c * 3 + 1], pu[c * 3 + 2]};
-                        const Rec v = {pv[c * 3], pv[c * 3 + 1], pv[c * 3 + 2]};
-                        acc += bt_pair(u, v);
+                        const uint32_t* q = pv - dd * (CN * 3) + c * 3;           // column X - (d0 + dd + minD)
+                        const Rec v = {q[0], q[1], q[2]};
+                        acc += bt_pair(u[c], v);
                     }
+                    const int pix = (int)acc.x + (int)acc.y;
+                    int hs = pix, tl = pix, tr = pix;
+#pragma unroll
+                    for (int k = 0; k < R; k++) {                   // neighbours' pixel costs, one more column per shift
+                        tl = __builtin_amdgcn_update_dpp(0, tl, 0x138, 0xf, 0xf, false);   // wave_shr:1
+                        tr = __builtin_amdgcn_update_dpp(0, tr, 0x130, 0xf, 0xf, false);   // wave_shl:1
+                        hs += tl + tr;
+                    }
+                    csum[dd] += hs - ring[s][dd];
+                    ring[s][dd] = hs;
+                    res[dd] = (short)min(csum[dd], SG_MAX_COST);
                 }
-                const int hs = (int)acc.x + (int)acc.y;           // horizontal window sum of row yy
-                csum += hs - ring[s];
-                ring[s] = hs;
-                if (n >= BS - 1) {
-                    const int y = y0 + n - (BS - 1);
-                    C[((size_t)y * a.w1 + x1) * a.D + d] = (int16_t)min(csum, SG_MAX_COST);
+                if (n >= BS - 1) {                               // block-uniform: a row of results goes out through LDS
+                    typedef short v8s __attribute__((ext_vector_type(8)));
+                    int16_t* tl_ = tile[n & 1];
+                    if (wave_active) {
+#pragma unroll
+                        for (int h = 0; h < DD / 8; h++) {
+                            v8s q;
+#pragma unroll
+                            for (int k = 0; k < 8; k++) q[k] = res[h * 8 + k];
+                            *reinterpret_cast<v8s*>(tl_ + lane * TP + wv * DD + h * 8) = q;
+                        }
+                    }
+                    __syncthreads();
+                    int16_t* dst = C + (size_t)(y0 + n - (BS - 1)) * a.w1 * a.D + dbase;
+                    const int part = threadIdx.x % TPC;
+#pragma unroll
+                    for (int col = threadIdx.x / TPC; col < OUTW; col += 256 / TPC) {
+                        const int xo = xt0 + col;
+                        if (xo < a.w1 && part * 8 < nd_blk)
+                            *reinterpret_cast<v8s*>(dst + (size_t)xo * a.D + part * 8) = *reinterpret_cast<const v8s*>(tl_ + (col + R) * TP + part * 8);
+                    }
+                    // (the other tile buffer is written next: one barrier per row is enough)
                 }
             }
         }
@@ -179,8 +230,6 @@ __device__ __forceinline__ int wave_min_i32(int v)
     const int c = __builtin_amdgcn_readlane(v, 32), e = __builtin_amdgcn_readlane(v, 48);
     return min(min(a, b), min(c, e));
 }
-
-template <int DPL> struct Vec16 { int16_t v[DPL]; };
 
 template <int DPL>
 __device__ __forceinline__ void load_costs(const int16_t* p, int (&o)[DPL])
@@ -422,15 +471,20 @@ int sg_reserve(void** p, size_t* have, size_t need, hipStream_t st)
 }
 
 template <int CN>
-hipError_t launch_cost(const CostArgs& a, int bs, dim3 grid, dim3 block, hipStream_t st)
+hipError_t launch_cost(const CostArgs& a, int bs, int n_images, hipStream_t st)
 {
+    // DD disparities per wave: 16 while the register ring (BS x DD) stays small, 8 for the tall windows
+    const int dd = bs <= 5 ? 16 : 8;
+    const int outw = 64 - 2 * (bs / 2);
+    const int nbands = (a.H + a.rows_per_band - 1) / a.rows_per_band;
+    const dim3 grid((a.w1 + outw - 1) / outw, (a.D + 4 * dd - 1) / (4 * dd), nbands * n_images), block(256);
     switch (bs) {
-    case 1: hipLaunchKernelGGL((sgbm_cost_kernel<1, CN>), grid, block, 0, st, a); break;
-    case 3: hipLaunchKernelGGL((sgbm_cost_kernel<3, CN>), grid, block, 0, st, a); break;
-    case 5: hipLaunchKernelGGL((sgbm_cost_kernel<5, CN>), grid, block, 0, st, a); break;
-    case 7: hipLaunchKernelGGL((sgbm_cost_kernel<7, CN>), grid, block, 0, st, a); break;
-    case 9: hipLaunchKernelGGL((sgbm_cost_kernel<9, CN>), grid, block, 0, st, a); break;
-    case 11: hipLaunchKernelGGL((sgbm_cost_kernel<11, CN>), grid, block, 0, st, a); break;
+    case 1: hipLaunchKernelGGL((sgbm_cost_kernel<1, CN, 16>), grid, block, 0, st, a); break;
+    case 3: hipLaunchKernelGGL((sgbm_cost_kernel<3, CN, 16>), grid, block, 0, st, a); break;
+    case 5: hipLaunchKernelGGL((sgbm_cost_kernel<5, CN, 16>), grid, block, 0, st, a); break;
+    case 7: hipLaunchKernelGGL((sgbm_cost_kernel<7, CN, 8>), grid, block, 0, st, a); break;
+    case 9: hipLaunchKernelGGL((sgbm_cost_kernel<9, CN, 8>), grid, block, 0, st, a); break;
+    case 11: hipLaunchKernelGGL((sgbm_cost_kernel<11, CN, 8>), grid, block, 0, st, a); break;
     default: return hipErrorInvalidValue;
     }
     return hipGetLastError();
@@ -624,10 +678,10 @@ extern "C" int adf_sgbm_compute_device(adf_sgbm_t* h, int n_pairs,
             CostArgs ca{rec1, rec2, rec_pair, Cv, volp, W, H, D, minD, minX1, w1, 0};
             // bands: the bs-1 warm-up rows are paid per band; enough workgroups to fill the chip when the image is small
             int rpb = 128;
-            while (rpb > 16 && (size_t)((H + rpb - 1) / rpb) * w1 * n < 4096) rpb >>= 1;
+            while (rpb > 16 && (size_t)((H + rpb - 1) / rpb) * ((w1 + 61) / 62) * ((D + 63) / 64) * n < 2048) rpb >>= 1;
             ca.rows_per_band = rpb;
-            const dim3 cgrid(w1, (H + rpb - 1) / rpb, n), cblock((D + 63) / 64 * 64);
-            hipError_t e = cn == 1 ? launch_cost<1>(ca, bs, cgrid, cblock, st) : launch_cost<3>(ca, bs, cgrid, cblock, st);
+            if ((size_t)((H + rpb - 1) / rpb) * n > 65535) return sg_fail(ADF_ESIZE, "too many images per call for the cost kernel's grid");
+            hipError_t e = cn == 1 ? launch_cost<1>(ca, bs, n, st) : launch_cost<3>(ca, bs, n, st);
             if (e != hipSuccess) return sg_fail(ADF_EHIP, hipGetErrorString(e));
             PathArgs pa{Cv, Sv, volp, W, H, D, minD, minX1, w1, P1, P2, ur, raw, (ptrdiff_t)W, (ptrdiff_t)raw_el, 0, 0, h->disp12};
             e = D <= 64 ? launch_paths<1>(pa, h->mode, n, st) : D <= 128 ? launch_paths<2>(pa, h->mode, n, st)

@@ -195,3 +195,17 @@ def test_create_defaults_run(adf, oracle):
     a, b = _pair(12, 40, 140, shift=7)
     m = adf.StereoSGBM.create(0, 32, 5)
     assert np.array_equal(m.compute(a, b), oracle.sgbm_compute(a, b, 32, 5, 0, 0, 0, 0, 0, mode=0, disp12_max_diff=0))
+
+
+def test_host_batch_with_row_padding(adf, oracle):
+    """adf_sgbm_compute_host on a batch of numpy pairs whose rows carry padding (strides larger than the width)."""
+    N, H, W = 2, 31, 120
+    pairs = [_pair(900 + i, H, W, 1, shift=4 + i) for i in range(N)]
+    bl = np.zeros((N, H, W + 9), np.uint8); br = np.zeros((N, H, W + 5), np.uint8)
+    for i, (l, r) in enumerate(pairs):
+        bl[i, :, :W] = l; br[i, :, :W] = r
+    out = np.full((N, H, W + 3), 555, np.int16)
+    _sgbm(adf, 32, 5).compute(bl[:, :, :W], br[:, :, :W], out[:, :, :W])
+    assert (out[:, :, W:] == 555).all()
+    for i, (l, r) in enumerate(pairs):
+        assert np.array_equal(out[i, :, :W], _exp(oracle, l, r, 32, 5))
