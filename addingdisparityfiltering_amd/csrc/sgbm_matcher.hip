@@ -231,6 +231,17 @@ __device__ __forceinline__ int wave_min_i32(int v)
     return min(min(a, b), min(c, e));
 }
 
+// num / den truncated toward zero (C semantics) for |num|, den < 2^24, den > 0: float quotient + one exact correction
+// step instead of the ~40-instruction integer division sequence.
+__device__ __forceinline__ int div_trunc_small(int num, int den)
+{
+    int q = (int)((float)num * __builtin_amdgcn_rcpf((float)den));       // truncation toward zero, off by at most one
+    int r = num - q * den;
+    if (num >= 0) { if (r < 0) { q--; } else if (r >= den) { q++; } }
+    else          { if (r > 0) { q++; } else if (r <= -den) { q--; } }
+    return q;
+}
+
 template <int DPL>
 __device__ __forceinline__ void load_costs(const int16_t* p, int (&o)[DPL])
 {
@@ -336,12 +347,13 @@ __global__ void __launch_bounds__(256) sgbm_path_kernel(PathArgs a)
             if (DIR == DIR_ADD) {
                 store_costs<DPL>(S + o, active, st);
             } else {
-                // winner: the FIRST disparity with the smallest S (stereo_binary_sgbm.cpp:519-528)
-                int bv = SG_MAX_COST, bk = 0;
+                // winner: the FIRST disparity with the smallest S (stereo_binary_sgbm.cpp:519-528) -- one wave minimum over
+                // the key (S << 10 | d): S is a sum of non-negative path costs, d < 1024
+                int key = 0x7fffffff;
 #pragma unroll
-                for (int k = 0; k < DPL; k++) if (active && st[k] < bv) { bv = st[k]; bk = k; }
-                const int minS = wave_min_i32(bv);
-                const int best = wave_min_i32((active && bv == minS) ? d0 + bk : (1 << 20));
+                for (int k = 0; k < DPL; k++) if (active) key = min(key, (st[k] << 10) | (d0 + k));
+                key = wave_min_i32(key);
+                const int minS = key >> 10, best = key & 1023;
                 bool reject = false;
                 if (a.ur > 0) {                                // stereo_binary_sgbm.cpp:543-547
 #pragma unroll
@@ -362,7 +374,7 @@ __global__ void __launch_bounds__(256) sgbm_path_kernel(PathArgs a)
                     const int sm = sS[wv][dm], s0 = sS[wv][d], sp = sS[wv][dp];
                     if (0 < d && d < a.D - 1) {                // stereo_binary_sgbm.cpp:584-591
                         const int denom2 = max(sm + sp - 2 * s0, 1);
-                        d = d * SG_DISP_SCALE + ((sm - sp) * SG_DISP_SCALE + denom2) / (denom2 * 2);
+                        d = d * SG_DISP_SCALE + div_trunc_small((sm - sp) * SG_DISP_SCALE + denom2, denom2 * 2);
                     } else
                         d *= SG_DISP_SCALE;
                     res = d + a.minD * SG_DISP_SCALE;           // :596
