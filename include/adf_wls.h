@@ -193,9 +193,10 @@ int adf_wls_profile_read(adf_wls_t* h, adf_kernel_time* out, int capacity, int* 
 int adf_fgs_create(adf_fgs_t** out, const uint8_t* guide, ptrdiff_t guide_stride, int guide_channels,
                    int w, int h, double lambda, double sigma_color, double lambda_attenuation,
                    int num_iter, int solver);
-/* The same with the guide already resident in HBM (a DEVICE pointer): nothing crosses PCIe and nothing
- * synchronises -- the guide copy and the weight kernel are queued on `stream`, which is also the stream the
- * handle's filter calls are expected on.  For device pipelines such as the second in-tree caller, which
+/* The same with the guide already resident in HBM (a DEVICE pointer): the guide never crosses PCIe -- its copy into
+ * the handle and the weight kernel are queued on `stream`, which is also the stream the handle's filter calls are
+ * expected on.  (Creation still uploads the 768 KB weight table built on the host with libm, FGS.cpp:663-675, and
+ * synchronises `stream` once for it.)  For device pipelines such as the second in-tree caller, which
  * smooths flow fields against an image it already holds (sparse_match_interpolators.cpp:202-203:
  * fastGlobalSmootherFilter(prevImage, flow, ...)). */
 int adf_fgs_create_device(adf_fgs_t** out, const uint8_t* guide, ptrdiff_t guide_stride, int guide_channels,
