@@ -81,7 +81,10 @@ def main(solver):
     traffic["_comment"] = ("HBM bytes per stereo pair and launch from rocprofv3 PMC passes (FETCH_SIZE doubled per the gfx950 "
                            "correction + WRITE_SIZE); sources: profiles/%s_wave_pmc_8pairs.csv (exact solver: the round it was "
                            "last collected in)" % ROUND)
-    traffic["_collected"] = "%s %s (%s solver)" % (ROUND, datetime.date.today().isoformat(), solver)
+    coll = traffic.get("_collected")
+    coll = coll if isinstance(coll, dict) else {}
+    coll["%s_cfg3" % solver] = "%s %s" % (ROUND, datetime.date.today().isoformat())
+    traffic["_collected"] = coll
     traffic["_kernel_sources_sha16"] = kernel_sources_sha16()
     traffic["_method"] = ("rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE in separate passes, bench.py --pairs 8 "
                           "--steps 1; read bytes = 2 * FETCH_SIZE KB * 1024 (gfx950 correction), write bytes = WRITE_SIZE KB * 1024; "
