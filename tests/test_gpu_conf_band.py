@@ -96,3 +96,22 @@ def test_band_kernel_equals_two_kernel_stage(adf, oracle):
         outs.append((out, f.getConfidenceMap()))
     assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1], outs[1][1])
     assert np.array_equal(outs[0][1], oracle.confidence(dl, dr, roi, 3, 24, threads=8))
+
+
+def _random_aligned_case(rng):
+    """Geometry the one-sweep kernel takes: frame width, ROI x and ROI width multiples of 4, radius 1..4."""
+    rw = 4 * int(rng.integers(2, 260)); rh = int(rng.integers(5, 140))
+    rx = 4 * int(rng.integers(0, 40)); ry = int(rng.integers(0, 9))
+    W = rx + rw + 4 * int(rng.integers(0, 30)); H = ry + rh + int(rng.integers(0, 9))
+    radius = int(rng.integers(1, 5))
+    if rh <= radius:
+        rh = radius + 1; H = max(H, ry + rh)
+    kind = str(rng.choice(["scene", "wide", "wild"]))
+    return W, H, (rx, ry, rw, rh), radius, kind, int(rng.integers(0, 80))
+
+
+@pytest.mark.parametrize("seed", range(40))
+def test_random_aligned_geometries(adf, oracle, seed):
+    rng = np.random.default_rng(7000 + seed)
+    W, H, roi, radius, kind, thresh = _random_aligned_case(rng)
+    _check(adf, oracle, W, H, roi, radius, kind, 7000 + seed, thresh)
