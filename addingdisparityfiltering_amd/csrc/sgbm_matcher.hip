@@ -332,7 +332,7 @@ __global__ void __launch_bounds__(256) sgbm_path_kernel(PathArgs a)
         for (int k = 0; k < DPL; k++) {
             const int below = k == 0 ? lm : L[k - 1], above = k == DPL - 1 ? lp : L[k + 1];
             const int m = min(min(L[k], below + a.P1), min(above + a.P1, delta));
-            Ln[k] = active ? sat16i(c[k] + m - minprev) : SG_MAX_COST;
+            Ln[k] = active ? sat16i(c[k] + m - delta) : SG_MAX_COST;      // :423: minus delta = min_k + P2, L in [C-P2, C]
             lmin = min(lmin, Ln[k]);
         }
 #pragma unroll
@@ -348,10 +348,10 @@ __global__ void __launch_bounds__(256) sgbm_path_kernel(PathArgs a)
                 store_costs<DPL>(S + o, active, st);
             } else {
                 // winner: the FIRST disparity with the smallest S (stereo_binary_sgbm.cpp:519-528) -- one wave minimum over
-                // the key (S << 10 | d): S is a sum of non-negative path costs, d < 1024
+                // the key S*1024 + d: |S| < 2^15 (S is negative as a rule: every path cost lies in [C-P2, C]), d < 1024
                 int key = 0x7fffffff;
 #pragma unroll
-                for (int k = 0; k < DPL; k++) if (active) key = min(key, (st[k] << 10) | (d0 + k));
+                for (int k = 0; k < DPL; k++) if (active) key = min(key, st[k] * 1024 + (d0 + k));
                 key = wave_min_i32(key);
                 const int minS = key >> 10, best = key & 1023;
                 bool reject = false;

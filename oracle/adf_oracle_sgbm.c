@@ -19,9 +19,14 @@
  *      interpolated extrema), the raw-intensity term scaled by 1/4; summed over the channels;
  *   3. block cost C(x,d): box sum of (2) over blockSize x blockSize, window clamped at the borders of the
  *      matchable area (stereo_binary_sgbm.cpp:205-276 is the same running-sum structure);
- *   4. path costs L_r(p,d) = C(p,d) + min(L_r(p-r,d), L_r(p-r,d-1)+P1, L_r(p-r,d+1)+P1, min_k L_r(p-r,k)+P2)
- *      - min_k L_r(p-r,k) (stereo_binary_sgbm.cpp:286-301, 419-446), neighbours outside [0,D) = SHRT_MAX (:323-324),
- *      path buffers start at zero (:191-194), costs kept in 16 bits with saturation; MODE_SGBM_3WAY uses three
+ *   4. path costs L_r(p,d) = C(p,d) + min(L_r(p-r,d), L_r(p-r,d-1)+P1, L_r(p-r,d+1)+P1, delta) - delta with
+ *      delta = min_k L_r(p-r,k) + P2 (stereo_binary_sgbm.cpp:286-301, 352, 419-446, 517): the code subtracts delta, i.e.
+ *      P2 MORE than formula 13 of the paper, so L lies in [C-P2, C] and S is the paper's sum minus npaths*P2 -- winner
+ *      and sub-pixel fit do not see the shift, the uniqueness test (:543-547) and the 16-bit saturation do (round 3:
+ *      rounds 1-2 subtracted min_k only).  Neighbours outside [0,D) = SHRT_MAX (:323-324),
+ *      path buffers start at zero (:191-194), costs kept in 16 bits with saturation (S is saturated after every path
+ *      here; the in-tree loop adds its four forward paths before it saturates, :443 -- the two differ only when a
+ *      partial sum leaves 16 bits and the full sum does not); MODE_SGBM_3WAY uses three
  *      paths: from the left, from the top, from the right; MODE_SGBM five (left, up-left, up, up-right, right: the
  *      forward sweep of :286-446 plus the backward one of :456-534), MODE_HH eight (two mirrored passes, :173-186);
  *   5. S = sum of the three paths; winner = the FIRST disparity with the smallest S (:519-528, strict <);
@@ -178,15 +183,15 @@ int adf_oracle_sgbm_block_costs(const adf_oracle_sgbm_params* p, const uint8_t* 
     return 0;
 }
 
-/* One step of formula 13 for all disparities: Lprev / Lout have D+2 entries, index 0 and D+1 are the d = -1 and
- * d = D guards (SHRT_MAX).  Returns min_k Lout[k]. */
+/* One step of the recurrence for all disparities (stereo_binary_sgbm.cpp:423: "L0 = Cpd + min(...) - delta0"): Lprev /
+ * Lout have D+2 entries, index 0 and D+1 are the d = -1 and d = D guards (SHRT_MAX).  Returns min_k Lout[k]. */
 static inline int path_step(const int16_t* Cp, const int16_t* Lprev, int minprev, int16_t* Lout, int D, int P1, int P2)
 {
     int mn = SGBM_MAX_COST;
     const int delta = minprev + P2;
     for (int d = 0; d < D; d++) {
         const int m = imin2(imin2((int)Lprev[d + 1], Lprev[d] + P1), imin2(Lprev[d + 2] + P1, delta));
-        const int L = sat_s16(Cp[d] + m - minprev);
+        const int L = sat_s16(Cp[d] + m - delta);
         Lout[d + 1] = (int16_t)L;
         mn = imin2(mn, L);
     }

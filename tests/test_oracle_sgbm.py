@@ -73,7 +73,7 @@ def naive_sgbm(img1, img2, nd, bs, md=0, P1=0, P2=0, cap=0, ur=0, mode=2, disp12
     def step(Cp, Lp, mp):
         big = np.array([SHRT_MAX])
         lm = np.concatenate([big, Lp[:-1]]) + P1; lp = np.concatenate([Lp[1:], big]) + P1
-        L = Cp + np.minimum(np.minimum(Lp, lm), np.minimum(lp, mp + P2)) - mp
+        L = Cp + np.minimum(np.minimum(Lp, lm), np.minimum(lp, mp + P2)) - (mp + P2)
         L = np.clip(L, -32768, SHRT_MAX)
         return L, L.min()
 
