@@ -9,6 +9,8 @@ from .ximgproc import (  # noqa: F401
     DisparityFilter,
     DisparityWLSFilter,
     FastGlobalSmootherFilter,
+    PATH_CONF_BAND,
+    PATH_FUSED_FIRST_PASS,
     SOLVER_EXACT,
     SOLVER_WAVE,
     StereoBM,

@@ -12,6 +12,7 @@ LIB_PATH = os.environ.get("ADF_WLS_LIB") or os.path.join(_HERE, "libadf_wls.so")
 
 ADF_OK, ADF_EBADARG, ADF_ESIZE, ADF_EHIP, ADF_ENOMEM, ADF_ENODEV = range(6)
 SOLVER_EXACT, SOLVER_WAVE = 0, 1
+PATH_CONF_BAND, PATH_FUSED_FIRST_PASS = 1, 2          # adf_wls_get_last_path bits (include/adf_wls.h)
 DEPTH_8U, DEPTH_16S, DEPTH_32F = 0, 3, 5
 
 
@@ -42,6 +43,7 @@ SYMBOLS = [
     ("adf_version", _i, []),
     ("adf_last_error", C.c_char_p, []),
     ("adf_device_count", _i, []),
+    ("adf_device_pci_bus_id", _i, [_i, C.c_char_p, _i]),
     ("adf_wls_create", _i, [C.POINTER(_vp), _i, _i, _i, _i, _i, _i]),
     ("adf_wls_destroy", None, [_vp]),
     ("adf_wls_set_lambda", _i, [_vp, _d]),
@@ -56,6 +58,7 @@ SYMBOLS = [
     ("adf_wls_set_solver", _i, [_vp, _i]),
     ("adf_wls_get_solver", _i, [_vp, C.POINTER(_i)]),
     ("adf_wls_get_last_solver", _i, [_vp, C.POINTER(_i)]),
+    ("adf_wls_get_last_path", _i, [_vp, C.POINTER(_i)]),
     ("adf_wls_filter_device", _i, _FILTER_DEV),
     ("adf_wls_filter_host", _i, _FILTER_DEV[:-1]),
     ("adf_wls_filter_scaled_device", _i, _FILTER_SCALED_DEV),
@@ -122,3 +125,10 @@ def lib():
 def check(rc):
     if rc != ADF_OK:
         raise AdfError(rc, lib().adf_last_error().decode("utf-8", "replace"))
+
+
+def device_pci_bus_id(device):
+    """PCI bus id string of HIP device `device` (adf_device_pci_bus_id)."""
+    buf = C.create_string_buffer(64)
+    check(lib().adf_device_pci_bus_id(int(device), buf, 64))
+    return buf.value.decode()

@@ -53,6 +53,14 @@ extern "C" int adf_device_count(void)
     return n;
 }
 
+extern "C" int adf_device_pci_bus_id(int device, char* buf, int len)
+{
+    if (!buf || len < 16) return fail(ADF_EBADARG, "adf_device_pci_bus_id: buffer of at least 16 bytes required");
+    buf[0] = 0;
+    HIP_TRY(hipDeviceGetPCIBusId(buf, len, device));
+    return ADF_OK;
+}
+
 // ----------------------------------------------------------------------------------------------
 // shared pieces
 // ----------------------------------------------------------------------------------------------
@@ -67,8 +75,15 @@ static Geom make_geom(int W, int H, int rx, int ry, int rw, int rh)
     size_t a = (size_t)round_up(rh, ADF_TILE_ROWS) * g.pw, b = (size_t)rw * g.ph;   // (the wave solver's pair plane holds rows in tiles)
     g.plane = ((a > b ? a : b) + 63) / 64 * 64;
     g.frame = (size_t)W * H;
+    // confidence plane: ROI column 0 16-byte aligned, >= 3 zero floats behind a row, pitch a multiple of 4 (adf_internal.h)
+    g.cx0 = (4 - (rx & 3)) & 3;
+    g.cpitch = round_up(W + g.cx0 + 3, 4);
+    g.cframe = (size_t)g.cpitch * H;
     return g;
 }
+
+// Confidence plane as a plain W-pitch frame (the low-resolution scratch map of the down-scaled path).
+static Geom plain_conf_layout(Geom g) { g.cx0 = 0; g.cpitch = g.W; g.cframe = g.frame; return g; }
 
 // RAII: run on the handle's device, restore the caller's on exit.
 struct DeviceScope {
@@ -271,6 +286,9 @@ struct adf_wls {
     // state of the last call
     adf_rect roi{0, 0, 0, 0};
     int last_W = 0, last_H = 0, last_pairs = 0;
+    int last_cpitch = 0, last_cx0 = 0;       // layout of the confidence planes of the last call (Geom::cpitch, cx0)
+    long long conf_sig[4] = {0, 0, 0, 0};    // (W, H, cx0, pairs) the confidence planes were last zeroed for
+    int last_path = 0;                       // ADF_PATH_* bits of the last call (adf_wls_get_last_path)
     // device memory
     Lut lut;
     DevBuf ws;    // per-chunk workspace
@@ -362,6 +380,7 @@ extern "C" int adf_wls_set_solver(adf_wls_t* h, int solver)
 }
 extern "C" int adf_wls_get_solver(const adf_wls_t* h, int* v) { NEED_HANDLE(h); if (v) *v = h->solver; return ADF_OK; }
 extern "C" int adf_wls_get_last_solver(const adf_wls_t* h, int* v) { NEED_HANDLE(h); if (v) *v = h->last_solver; return ADF_OK; }
+extern "C" int adf_wls_get_last_path(const adf_wls_t* h, int* v) { NEED_HANDLE(h); if (v) *v = h->last_path; return ADF_OK; }
 
 extern "C" int adf_wls_get_device(const adf_wls_t* h, int* device) { NEED_HANDLE(h); if (device) *device = h->device; return ADF_OK; }
 extern "C" int adf_wls_get_roi(const adf_wls_t* h, adf_rect* roi) { NEED_HANDLE(h); if (roi) *roi = h->roi; return ADF_OK; }
@@ -375,6 +394,21 @@ extern "C" int adf_wls_sync(adf_wls_t* h, void* stream)
     NEED_HANDLE(h);
     DeviceScope ds(h->device);
     HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+    return ADF_OK;
+}
+
+// The confidence planes of a call: n_pairs planes in Geom's cpitch layout.  Whatever lies outside the ROI -- frame
+// pixels and row padding alike -- must read as zero; frame pixels are written by the kernels of every call, the padding
+// never is, so the buffer is cleared whenever the layout it was last used with changes.
+static int ensure_conf_planes(adf_wls* h, const Geom& g, int n_pairs, hipStream_t st)
+{
+    int rc = h->conf.reserve(g.cframe * sizeof(float) * (size_t)n_pairs, st);
+    if (rc) return rc;
+    const long long sig[4] = {g.W, g.H, g.cx0, n_pairs};
+    if (memcmp(sig, h->conf_sig, sizeof(sig)) != 0) {
+        HIP_TRY(hipMemsetAsync(h->conf.p, 0, h->conf.bytes, st));
+        memcpy(h->conf_sig, sig, sizeof(sig));
+    }
     return ADF_OK;
 }
 
@@ -423,6 +457,7 @@ static int wls_filter_impl(adf_wls_t* h, int n_pairs,
     DeviceScope ds(h->device);
     const Geom g = make_geom(W, H, roi.x, roi.y, roi.width, roi.height);
     h->roi = roi; h->last_W = W; h->last_H = H; h->last_pairs = n_pairs;
+    h->last_cpitch = g.cpitch; h->last_cx0 = g.cx0; h->last_path = 0;
 
     int rc = h->lut.ensure((float)h->sigma_color, st);
     if (rc) return rc;
@@ -435,7 +470,7 @@ static int wls_filter_impl(adf_wls_t* h, int n_pairs,
     bool band = false;
     if (conf && !conf_given && wave && h->conf_band && conf_band_fits(g, h->disc_radius)) {
         WavePassArgs probe{};
-        probe.conf_in = (const float*)h->conf.p; probe.conf_frame = g.frame; probe.conf_pitch = W; probe.conf_x0 = roi.x; probe.conf_y0 = roi.y;
+        probe.conf_in = (const float*)h->conf.p; probe.conf_frame = g.cframe; probe.conf_pitch = g.cpitch; probe.conf_x0 = g.cx0 + roi.x; probe.conf_y0 = roi.y;
         probe.dl_in = dispL; probe.dl_stride = sL; probe.dl_pair_stride = psL; probe.dl_x0 = roi.x; probe.dl_y0 = roi.y;
         probe.len = g.rw;
         // (h->conf.p may still be null or about to be re-allocated: hipMalloc returns 256-byte aligned memory either way)
@@ -447,7 +482,7 @@ static int wls_filter_impl(adf_wls_t* h, int n_pairs,
     if (chunk < 1) chunk = 1;
     if (chunk > n_pairs) chunk = n_pairs;
     if ((rc = h->ws.reserve(per_pair * (size_t)chunk, st))) return rc;
-    if (conf && !conf_given && (rc = h->conf.reserve(g.frame * sizeof(float) * (size_t)n_pairs, st))) return rc;
+    if (conf && !conf_given && (rc = ensure_conf_planes(h, g, n_pairs, st))) return rc;
 
     {
         const long long sig[8] = {W, H, roi.x, roi.y, roi.width, roi.height, (long long)band * 4 + (long long)wave * 2 + conf, chunk};
@@ -511,7 +546,7 @@ static int wls_filter_impl(adf_wls_t* h, int n_pairs,
         if (conf) {
             const int16_t* dRp = (const int16_t*)((const char*)dispR + (ptrdiff_t)first * psR);
             const int rrx = W - (roi.x + roi.width);                       // DF.cpp:202
-            float* confp = (float*)h->conf.p + (size_t)first * g.frame;
+            float* confp = (float*)h->conf.p + (size_t)first * g.cframe;
             const int thresh = (int)(1.0f * h->lrc_thresh);                // DF.cpp:318 (resize_factor 1)
             DiscArgs da{};
             da.disp[0] = dL; da.stride[0] = sL; da.pair_stride[0] = psL; da.rx[0] = roi.x; da.dst[0] = cL;
@@ -526,7 +561,7 @@ static int wls_filter_impl(adf_wls_t* h, int n_pairs,
                     ProfScope ps(prof, K_FILL, 2.0 * (F - P), 2.0 * (F - P), st);
                     HIP_TRY(launch_outside(oa, n, st));                    // DF.cpp:284
                 }
-                fuse.conf_in = confp; fuse.conf_frame = g.frame; fuse.conf_pitch = W; fuse.conf_x0 = roi.x; fuse.conf_y0 = roi.y;
+                fuse.conf_in = confp; fuse.conf_frame = g.cframe; fuse.conf_pitch = g.cpitch; fuse.conf_x0 = g.cx0 + roi.x; fuse.conf_y0 = roi.y;
                 fuse.dl_in = dL; fuse.dl_stride = sL; fuse.dl_pair_stride = psL; fuse.dl_x0 = roi.x; fuse.dl_y0 = roi.y;
                 fuse.len = g.rw;
                 if (!(wave && wave_hpass_can_fuse(fuse))) {
@@ -539,12 +574,13 @@ static int wls_filter_impl(adf_wls_t* h, int n_pairs,
                 // wave path: right map, then left map + LRC + x255 in one sweep (cL never hits memory);
                 // the first horizontal pass forms conf*disp itself when alignment allows
                 da.only_view = 1;
-                fuse.conf_in = confp; fuse.conf_frame = g.frame; fuse.conf_pitch = W; fuse.conf_x0 = roi.x; fuse.conf_y0 = roi.y;
+                fuse.conf_in = confp; fuse.conf_frame = g.cframe; fuse.conf_pitch = g.cpitch; fuse.conf_x0 = g.cx0 + roi.x; fuse.conf_y0 = roi.y;
                 fuse.dl_in = dL; fuse.dl_stride = sL; fuse.dl_pair_stride = psL; fuse.dl_x0 = roi.x; fuse.dl_y0 = roi.y;
                 fuse.len = g.rw;
                 const bool fused_h = wave_hpass_can_fuse(fuse);
                 if (!fused_h) fuse = WavePassArgs{};
                 if (band && !fused_h) return fail(ADF_EHIP, "internal: confidence kernel selection and first-pass fusion disagree");
+                if (band) h->last_path |= ADF_PATH_CONF_BAND;
                 if (band) {
                     // both views, LRC and x255 in one band sweep: the right view's map lives in LDS only
                     ConfBandArgs ba{dL, sL, psL, dRp, sR, psR, confp, g, rrx, thresh, h->disc_radius, h->roll_off, 0};
@@ -579,6 +615,7 @@ static int wls_filter_impl(adf_wls_t* h, int n_pairs,
                 }
             }
             if (fork_weights) HIP_TRY(hipStreamWaitEvent(st, h->ev_join, 0));
+            if (wave && fuse.conf_in) h->last_path |= ADF_PATH_FUSED_FIRST_PASS;
             FinalOut fo{EPI_WLS_CONF, o, sO, psO, roi.x, roi.y, 1, 0};
             rc = wave ? run_passes_wave(g, p, 2, (float)h->lambda, (float)h->atten, h->num_iter, fo, n, st, prof,
                                         fuse.conf_in ? &fuse : nullptr)
@@ -655,9 +692,10 @@ extern "C" int adf_wls_filter_scaled_device(adf_wls_t* h, int n_pairs,
     float* cl = (float*)(dhi + (size_t)n_pairs * dhi_bytes);
     float* cr = cl + (size_t)n_pairs * lo;
     float* clo = cr + (size_t)n_pairs * lo;
+    const Geom ghi = make_geom(W, H, rhi.x, rhi.y, rhi.width, rhi.height);   // the geometry wls_filter_impl will derive
     if (conf) {
-        if ((rc = h->conf.reserve(hi * sizeof(float) * (size_t)n_pairs, st))) return rc;
-        const Geom glo = make_geom(dW, dH, rlo.x, rlo.y, rlo.width, rlo.height);
+        if ((rc = ensure_conf_planes(h, ghi, n_pairs, st))) return rc;
+        const Geom glo = plain_conf_layout(make_geom(dW, dH, rlo.x, rlo.y, rlo.width, rlo.height));
         const int rrx = dW - (rlo.x + rlo.width);                          // DF.cpp:202
         DiscArgs da{};
         da.disp[0] = dispL; da.stride[0] = sL; da.pair_stride[0] = psL; da.rx[0] = rlo.x; da.dst[0] = cl;
@@ -677,8 +715,8 @@ extern "C" int adf_wls_filter_scaled_device(adf_wls_t* h, int n_pairs,
             LrcArgs la{dispL, sL, psL, dispR, sR, psR, cl, cr, clo, nullptr, 0, 0, 0, nullptr, nullptr, glo, rrx, thresh_lo, ORIENT_N};
             HIP_TRY(launch_lrc_prologue(la, n_pairs, st));                 // DF.cpp:208-209
         }
-        ResizeArgs rc32{clo, (ptrdiff_t)dW * 4, (ptrdiff_t)(lo * 4), dW, dH, h->conf.p, (ptrdiff_t)W * 4, (ptrdiff_t)(hi * 4), W, H,
-                        (double)dW / W, (double)dH / H, 1.0f, 0};
+        ResizeArgs rc32{clo, (ptrdiff_t)dW * 4, (ptrdiff_t)(lo * 4), dW, dH, (float*)h->conf.p + ghi.cx0, (ptrdiff_t)ghi.cpitch * 4,
+                        (ptrdiff_t)(ghi.cframe * 4), W, H, (double)dW / W, (double)dH / H, 1.0f, 0};
         HIP_TRY(launch_resize_linear(rc32, n_pairs, st));                  // DF.cpp:274
     }
     ResizeArgs r16{dispL, sL, psL, dW, dH, dhi, (ptrdiff_t)W * 2, (ptrdiff_t)dhi_bytes, W, H, (double)dW / W, (double)dH / H, x_ratio, 1};
@@ -782,8 +820,8 @@ static int conf_copy(adf_wls_t* h, int pair, float* dst, ptrdiff_t stride, hipMe
         return fail(ADF_EBADARG, "no confidence map: filter() has not run with use_confidence");
     if (pair < 0 || pair >= h->last_pairs) return fail(ADF_EBADARG, "pair %d out of range [0,%d)", pair, h->last_pairs);
     if (stride < (ptrdiff_t)h->last_W * 4) return fail(ADF_ESIZE, "confidence stride smaller than a row");
-    const float* src = (const float*)h->conf.p + (size_t)pair * h->last_W * h->last_H;
-    HIP_TRY(hipMemcpy2DAsync(dst, stride, src, (size_t)h->last_W * 4, (size_t)h->last_W * 4, h->last_H, kind, st));
+    const float* src = (const float*)h->conf.p + (size_t)pair * h->last_cpitch * h->last_H + h->last_cx0;
+    HIP_TRY(hipMemcpy2DAsync(dst, stride, src, (size_t)h->last_cpitch * 4, (size_t)h->last_W * 4, h->last_H, kind, st));
     return ADF_OK;
 }
 

@@ -21,6 +21,12 @@ struct Geom {
     int pw, ph;         // padded pitches (floats)
     size_t plane;       // floats per pair per ROI plane = max(rh*pw, rw*ph)
     size_t frame;       // floats per pair per full-frame plane = W*H
+    // The confidence plane (library-owned; getConfidenceMap copies it out) has a layout of its own: frame pixel (i, j)
+    // at cframe*pair + i*cpitch + cx0 + j, with cx0 chosen so that ROI column 0 is 16-byte aligned for ANY ROI x,
+    // cpitch a multiple of 4 floats that leaves at least 3 zero floats behind frame column W-1 (the fused first row
+    // pass reads whole float4s: what it over-reads is zero), zeros everywhere outside the ROI.
+    int cpitch, cx0;
+    size_t cframe;      // floats per pair of the confidence plane = cpitch*H
 };
 
 // Destination layout of a plane-writing kernel.
@@ -62,7 +68,7 @@ struct ConfLeftArgs {
     const int16_t* dL; ptrdiff_t sL, psL; // bytes
     const int16_t* dR; ptrdiff_t sR, psR;
     const float* cR;                      // full-frame, W pitch
-    float* conf;                          // full-frame confidence (x255); only ROI pixels are written
+    float* conf;                          // confidence plane (x255; Geom::cpitch layout); only ROI pixels are written
     float* U0; float* U1;                 // ORIENT_PAIR plane at U0 (may be null: first pass reads conf/dL itself); U1 unused
     Geom g; int rrx; int thresh;
     int radius; float roll_off;
@@ -73,7 +79,7 @@ struct ConfLeftArgs {
 struct ConfBandArgs {
     const int16_t* dL; ptrdiff_t sL, psL; // bytes
     const int16_t* dR; ptrdiff_t sR, psR;
-    float* conf;                          // full-frame confidence (x255); only ROI pixels are written
+    float* conf;                          // confidence plane (x255; Geom::cpitch layout); only ROI pixels are written
     Geom g; int rrx; int thresh;
     int radius; float roll_off;
     int rows_per_band;
@@ -90,7 +96,7 @@ struct LrcArgs {
     const int16_t* dL; ptrdiff_t sL, psL; // bytes
     const int16_t* dR; ptrdiff_t sR, psR;
     const float* cL; const float* cR; // full-frame discontinuity maps
-    float* conf;                      // full-frame confidence (x255), zero outside ROI
+    float* conf;                      // confidence plane (x255; Geom::cpitch layout), zero outside ROI
     int16_t* out; ptrdiff_t sO, psO; int16_t fill; // filtered map: `fill` outside the ROI (DF.cpp:284); may be null
     float* U0; float* U1;             // ROI planes: conf*disp, conf
     Geom g; int rrx;                  // right ROI x (DF.cpp:202)
@@ -104,7 +110,7 @@ struct PlainPrologueArgs {
     int depth, cn, c;                               // adf_depth code, channel count, channel index
     float* U0; Geom g; int orient;
     // optional confidence weighting (down-scaled path, DF.cpp:286-290 on the resized maps):
-    // U0 = conf*float(src), U1 = conf, conf read from a full-frame plane of pitch g.W
+    // U0 = conf*float(src), U1 = conf, conf read from a confidence plane (Geom::cpitch layout)
     const float* conf; float* U1;
     // or a second source channel as the second right-hand side (generic FGS on the wave solver: channel
     // pairs share one factorisation): U1 = float(src channel c2) when pair2 is set (conf must be null)

@@ -245,7 +245,7 @@ __global__ void __launch_bounds__(NT) conf_left_kernel(ConfLeftArgs a)
     const char* baseL = reinterpret_cast<const char*>(a.dL) + (ptrdiff_t)pz * a.psL;
     const char* baseR = reinterpret_cast<const char*>(a.dR) + (ptrdiff_t)pz * a.psR;
     const float* cR = a.cR + pz * g.frame;
-    float* conf = a.conf + pz * g.frame;
+    float* conf = a.conf + pz * g.cframe + g.cx0;
     const int gx_in = reflect101(x_out0 - RT + tid, g.rw);
     const int gx_out = x_out0 + tid - RT;                          // == gx_in for writer threads
     const bool writer = tid >= RT && tid < NT - RT && gx_out < g.rw;
@@ -332,7 +332,7 @@ __global__ void __launch_bounds__(NT) conf_left_kernel(ConfLeftArgs a)
                         else c = 0.0f;                                   // DF.cpp:337
                     }
                     c = 255.0f * c;                               // DF.cpp:209
-                    ADF_ST(&conf[(size_t)i_abs * g.W + j_abs], c);
+                    ADF_ST(&conf[(size_t)i_abs * g.cpitch + j_abs], c);
                     if (WRITE_U) {
                         const size_t o = pz * 2 * g.plane + pair_index(oy, gx_out, g.pw);   // ORIENT_PAIR
                         a.U0[o] = c * (float)d;                   // DF.cpp:289-290
@@ -355,8 +355,8 @@ __global__ void __launch_bounds__(NT) conf_left_kernel(ConfLeftArgs a)
 // HBM sees dL and dR once (plus 2*RT halo rows per band) and the confidence map: 8 B per ROI pixel.
 //
 // Layout of the work: lane = 4 adjacent columns (one 8-byte load per view and row), wave = 64 lanes = 248
-// output columns (the first and last lane only supply the horizontal halo, so a wave never needs another
-// wave's sums).  Sums run VERTICAL first: each lane keeps the raw values of the last K = 2*RT+1 rows of its
+// output columns for radius <= 4, 240 for radius 5..8 (the first and last ceil(radius/4) lanes only supply the
+// horizontal halo, so a wave never needs another wave's sums).  Sums run VERTICAL first: each lane keeps the raw values of the last K = 2*RT+1 rows of its
 // columns packed in registers and updates the column sums (sum d, and sum d^2 split in 16-bit halves: all
 // 32-bit integer, exact) by new row minus oldest row; the horizontal window is then a sliding sum over the
 // lane's own four column sums and the neighbours' edge columns, fetched with whole-wave DPP shifts (no LDS, no
@@ -366,8 +366,10 @@ __global__ void __launch_bounds__(NT) conf_left_kernel(ConfLeftArgs a)
 // One workgroup barrier per row (right map written -> gathered).
 // ---------------------------------------------------------------------------------------
 constexpr int CB_COLS = 4;
-constexpr int CB_WOUT = (64 - 2) * CB_COLS;   // output columns per wave
+#define CB_HALO(RT) (((RT) + CB_COLS - 1) / CB_COLS)                 // halo lanes on each side of a wave
+#define CB_WOUT(RT) ((64 - 2 * CB_HALO(RT)) * CB_COLS)               // output columns per wave: 248 (radius <= 4), 240 (5..8)
 constexpr int CB_MAX_WAVES = 16;
+constexpr int CB_MAX_RADIUS = 2 * CB_COLS;
 
 __device__ __forceinline__ int dpp_from_prev(int v) { return __builtin_amdgcn_update_dpp(0, v, 0x138, 0xf, 0xf, false); }  // wave_shr:1
 __device__ __forceinline__ int dpp_from_next(int v) { return __builtin_amdgcn_update_dpp(0, v, 0x130, 0xf, 0xf, false); }  // wave_shl:1
@@ -393,14 +395,36 @@ __device__ __forceinline__ float disc_value(int s1, int lo, int hi, double scale
     return v < 0.0f ? 0.0f : v;
 }
 
-// The four map values of a lane's columns from its column sums.  Horizontal window of output column q (0..3):
-// own columns max(0,q-RT) .. min(3,q+RT) -- differences of the lane's prefix sums -- plus the last RT-q columns of the
-// previous lane and the first q+RT-3 columns of the next one, each fetched as ONE partial sum by a whole-wave DPP shift
-// folded into the add that consumes it (every fetched value has a single use).
+// The four map values of a lane's columns from its column sums.  Horizontal window of output column q (0..3): virtual
+// columns q-RT .. q+RT relative to the lane's first column, i.e. the lane's own columns max(0,q-RT) .. min(3,q+RT) --
+// differences of the lane's prefix sums -- plus, from the j-th lane before it (columns -4j .. -4j+3), its LAST
+// min(4, 4-4j+RT-q) columns and, from the j-th lane after it, its FIRST min(4, q+RT-4j+1) columns; j runs to
+// CB_HALO(RT) = ceil(RT/4) (one lane for radius <= 4, two for radius 5..8: round 3).  Every neighbour contribution is
+// ONE partial sum fetched by whole-wave DPP shifts (wave_shr:1 / wave_shl:1, applied j times); where a fetched value
+// has a single use the compiler folds the shift into the add that consumes it.
+template <int J> __device__ __forceinline__ int dpp_prev_n(int v) { if constexpr (J <= 0) return v; else return dpp_prev_n<J - 1>(dpp_from_prev(v)); }
+template <int J> __device__ __forceinline__ int dpp_next_n(int v) { if constexpr (J <= 0) return v; else return dpp_next_n<J - 1>(dpp_from_next(v)); }
+
+template <int RT, int J>
+__device__ __forceinline__ void band_neighbours(const int (&p1)[CB_COLS + 1], const int (&pl)[CB_COLS + 1], const int (&ph)[CB_COLS + 1],
+                                                int q, int& h1, int& hl, int& hh)
+{
+    if constexpr (J >= 1) {
+        const int mp = 4 - 4 * J + RT - q, mn = q + RT - 4 * J + 1;      // columns of lane -J / lane +J inside the window
+        const int m = mp < 0 ? 0 : (mp > CB_COLS ? CB_COLS : mp), m2 = mn < 0 ? 0 : (mn > CB_COLS ? CB_COLS : mn);
+        if (m > 0) {
+            h1 += dpp_prev_n<J>(p1[CB_COLS] - p1[CB_COLS - m]); hl += dpp_prev_n<J>(pl[CB_COLS] - pl[CB_COLS - m]);
+            hh += dpp_prev_n<J>(ph[CB_COLS] - ph[CB_COLS - m]);
+        }
+        if (m2 > 0) { h1 += dpp_next_n<J>(p1[m2]); hl += dpp_next_n<J>(pl[m2]); hh += dpp_next_n<J>(ph[m2]); }
+        band_neighbours<RT, J - 1>(p1, pl, ph, q, h1, hl, hh);
+    }
+}
+
 template <int RT>
 __device__ __forceinline__ void band_row_values(const ColSum (&V)[CB_COLS], double scale, float roll_off, float (&out)[CB_COLS])
 {
-    static_assert(RT >= 1 && RT <= CB_COLS, "the halo must fit one lane");
+    static_assert(RT >= 1 && RT <= 2 * CB_COLS, "the halo must fit two lanes");
     int p1[CB_COLS + 1], pl[CB_COLS + 1], ph[CB_COLS + 1];           // prefix sums P[i] = V[0] + .. + V[i-1]
     p1[0] = pl[0] = ph[0] = 0;
 #pragma unroll
@@ -409,15 +433,7 @@ __device__ __forceinline__ void band_row_values(const ColSum (&V)[CB_COLS], doub
     for (int q = 0; q < CB_COLS; q++) {
         const int a = q - RT > 0 ? q - RT : 0, b = (q + RT < CB_COLS - 1 ? q + RT : CB_COLS - 1) + 1;
         int h1 = p1[b] - p1[a], hl = pl[b] - pl[a], hh = ph[b] - ph[a];
-        if (q < RT) {                                                // suffix of the previous lane: its last RT-q columns
-            const int m = RT - q;
-            h1 += dpp_from_prev(p1[CB_COLS] - p1[CB_COLS - m]); hl += dpp_from_prev(pl[CB_COLS] - pl[CB_COLS - m]);
-            hh += dpp_from_prev(ph[CB_COLS] - ph[CB_COLS - m]);
-        }
-        if (q + RT > CB_COLS - 1) {                                  // prefix of the next lane: its first q+RT-3 columns
-            const int m = q + RT - (CB_COLS - 1);
-            h1 += dpp_from_next(p1[m]); hl += dpp_from_next(pl[m]); hh += dpp_from_next(ph[m]);
-        }
+        band_neighbours<RT, CB_HALO(RT)>(p1, pl, ph, q, h1, hl, hh);
         out[q] = disc_value(h1, hl, hh, scale, roll_off);
     }
 }
@@ -439,8 +455,9 @@ __global__ void __launch_bounds__(64 * CB_MAX_WAVES) conf_band_kernel(ConfBandAr
     const int y0 = blockIdx.x * a.rows_per_band;
     const int rows_out = min(a.rows_per_band, g.rh - y0);
     const int nrows = rows_out + 2 * RT;               // input rows this band consumes
-    const int vbase = wv * CB_WOUT + CB_COLS * (lane - 1);            // first (virtual) column of this lane
-    const bool out_lane = lane >= 1 && lane <= 62 && vbase < rw;      // owns output columns vbase .. vbase+3 (those < rw)
+    constexpr int HL = CB_HALO(RT);
+    const int vbase = wv * CB_WOUT(RT) + CB_COLS * (lane - HL);       // first (virtual) column of this lane
+    const bool out_lane = lane >= HL && lane <= 63 - HL && vbase < rw;  // owns output columns vbase .. vbase+3 (those < rw)
 
     // which real columns feed this lane's four virtual columns: one 8-byte window [lcol, lcol+4) of the row and a
     // byte permute (identity for every lane away from the two image edges)
@@ -470,7 +487,7 @@ __global__ void __launch_bounds__(64 * CB_MAX_WAVES) conf_band_kernel(ConfBandAr
     const char* baseL = reinterpret_cast<const char*>(a.dL) + (ptrdiff_t)pz * a.psL + (ptrdiff_t)g.ry * a.sL + (ptrdiff_t)g.rx * 2;
     const char* baseR = reinterpret_cast<const char*>(a.dR) + (ptrdiff_t)pz * a.psR + (ptrdiff_t)g.ry * a.sR + (ptrdiff_t)a.rrx * 2;
     const unsigned lane_off = (unsigned)lcol * 2u;
-    float* conf = a.conf + pz * g.frame + (size_t)g.ry * g.W + g.rx;
+    float* conf = a.conf + pz * g.cframe + (size_t)g.ry * g.cpitch + g.cx0 + g.rx;   // 16-byte aligned (Geom::cx0)
     const double scale = 1.0 / ((double)K * (double)K);
     const int right_end = a.rrx + rw;
 
@@ -542,7 +559,7 @@ __global__ void __launch_bounds__(64 * CB_MAX_WAVES) conf_band_kernel(ConfBandAr
                         const float chit = abs(d + dr) < a.thresh ? cmin : 0.0f;   // DF.cpp:337
                         res[q] = 255.0f * (hit ? chit : cl[q]);          // DF.cpp:209
                     }
-                    float* dst = conf + (size_t)oy * g.W + vbase;
+                    float* dst = conf + (size_t)oy * g.cpitch + vbase;
                     if (vbase + CB_COLS <= rw) {
                         const v4f_u o = {res[0], res[1], res[2], res[3]};
                         __builtin_nontemporal_store(o, reinterpret_cast<v4f_u*>(dst));
@@ -578,7 +595,7 @@ __global__ void __launch_bounds__(NT) outside_kernel(OutsideArgs a)
         if (a.out)
             reinterpret_cast<int16_t*>(reinterpret_cast<char*>(a.out) + (ptrdiff_t)blockIdx.z * a.pair_stride +
                                        (ptrdiff_t)i * a.stride)[j] = a.fill;
-        if (a.conf) a.conf[(size_t)blockIdx.z * g.frame + (size_t)i * g.W + j] = 0.0f;
+        if (a.conf) a.conf[(size_t)blockIdx.z * g.cframe + (size_t)i * g.cpitch + g.cx0 + j] = 0.0f;
     }
 }
 
@@ -598,7 +615,7 @@ __global__ void __launch_bounds__(NT) lrc_prologue_kernel(LrcArgs a)
     const char* pR = reinterpret_cast<const char*>(a.dR) + (ptrdiff_t)pz * a.psR;
     const float* cL = a.cL + pz * g.frame;
     const float* cR = a.cR + pz * g.frame;
-    float* conf = a.conf + pz * g.frame;
+    float* conf = a.conf + pz * g.cframe + g.cx0;
     const bool pair = a.orient == ORIENT_PAIR;
     float* U0 = a.U0 ? a.U0 + pz * (pair ? 2 : 1) * g.plane : nullptr;   // null: confidence only (down-scaled path)
     float* U1 = a.U0 ? (pair ? U0 + ADF_STRIP : a.U1 + pz * g.plane) : nullptr;
@@ -649,7 +666,7 @@ __global__ void __launch_bounds__(NT) lrc_prologue_kernel(LrcArgs a)
             u0 = c * (float)d;                                          // DF.cpp:289-290
         }
         if (in_frame) {
-            conf[(size_t)i * g.W + j] = c;
+            conf[(size_t)i * g.cpitch + j] = c;
             if (a.out && !in_roi)                                          // DF.cpp:284
                 reinterpret_cast<int16_t*>(reinterpret_cast<char*>(a.out) + (ptrdiff_t)pz * a.psO +
                                            (ptrdiff_t)i * a.sO)[j] = a.fill;
@@ -689,7 +706,7 @@ __global__ void __launch_bounds__(NT) plain_prologue_kernel(PlainPrologueArgs a)
     const int x0 = blockIdx.x * TX, y0 = blockIdx.y * TY; // ROI coordinates
     const size_t pz = blockIdx.z;
     const char* pL = reinterpret_cast<const char*>(a.src) + (ptrdiff_t)pz * a.pair_stride;
-    const float* cf = a.conf ? a.conf + pz * g.frame : nullptr;
+    const float* cf = a.conf ? a.conf + pz * g.cframe + g.cx0 : nullptr;
     const bool pair = a.orient == ORIENT_PAIR;          // only with confidence weighting (two right-hand sides)
     float* U0 = a.U0 + pz * (pair ? 2 : 1) * g.plane;
     const bool two = a.conf != nullptr || a.pair2;      // two right-hand sides
@@ -716,7 +733,7 @@ __global__ void __launch_bounds__(NT) plain_prologue_kernel(PlainPrologueArgs a)
                 else u1 = reinterpret_cast<const float*>(row)[e2];
             }
             if (cf) {                                                                    // DF.cpp:286-290
-                u1 = cf[(size_t)(g.ry + i) * g.W + g.rx + j];
+                u1 = cf[(size_t)(g.ry + i) * g.cpitch + g.rx + j];
                 u0 = u1 * u0;
             }
         }
@@ -782,12 +799,10 @@ hipError_t launch_discontinuity(const DiscArgs& a, int n_pairs, hipStream_t st)
     }
     static_assert(TX == 64 && TY == 32 && NT == 256, "discontinuity_kernel assumes a 64x32 tile and 256 threads");
     const size_t lds = disc_lds_bytes(a.radius);
-    static size_t configured = 0;
-    if (lds > 48 * 1024 && lds > configured) {
+    if (lds > 48 * 1024) {      // per function AND device: set whenever needed, never cached process-wide
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(discontinuity_kernel),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
-        configured = lds;
     }
     dim3 grid((a.rw + TX - 1) / TX, (a.rh + TY - 1) / TY, (a.only_view >= 0 ? 1 : 2) * n_pairs);
     hipLaunchKernelGGL(discontinuity_kernel, grid, dim3(NT), lds, st, a);
@@ -800,15 +815,15 @@ static inline size_t conf_band_lds(int rw, int radius) { const size_t rwp = (siz
 
 bool conf_band_fits(const Geom& g, int radius)
 {
-    return radius >= 1 && radius <= 4 && g.rw >= 8 && g.rw <= CB_MAX_WAVES * CB_WOUT && g.rh > radius &&
-           conf_band_lds(g.rw, radius) <= 150 * 1024;
+    return radius >= 1 && radius <= CB_MAX_RADIUS && g.rw >= 8 && g.rw > radius && g.rw <= CB_MAX_WAVES * CB_WOUT(radius) &&
+           g.rh > radius && conf_band_lds(g.rw, radius) <= 150 * 1024;
 }
 
 hipError_t launch_conf_band(const ConfBandArgs& a0, int n_pairs, hipStream_t st)
 {
     if (!conf_band_fits(a0.g, a0.radius)) return hipErrorInvalidValue;
     ConfBandArgs a = a0;
-    const int waves = (a.g.rw + CB_WOUT - 1) / CB_WOUT;
+    const int waves = (a.g.rw + CB_WOUT(a.radius) - 1) / CB_WOUT(a.radius);
     // bands: tall (the 2*RT halo rows and the K-row ramp are paid per band), but enough workgroups for two rounds
     // of the chip's 256 CUs when the batch allows it
     int bands = (512 + n_pairs - 1) / n_pairs;
@@ -818,18 +833,17 @@ hipError_t launch_conf_band(const ConfBandArgs& a0, int n_pairs, hipStream_t st)
     a.rows_per_band = rpb;
     const dim3 grid((a.g.rh + rpb - 1) / rpb, n_pairs), block(64 * waves);
     const size_t lds = conf_band_lds(a.g.rw, a.radius);
-    static size_t configured[5] = {0, 0, 0, 0, 0};
+    // (the attribute belongs to the function ON THE CURRENT DEVICE and a process may hold handles on several: no cache)
 #define ADF_CB(RR)                                                                                          \
     case RR:                                                                                                \
-        if (lds > 48 * 1024 && lds > configured[RR]) {                                                      \
+        if (lds > 48 * 1024) {                                                                              \
             hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conf_band_kernel<RR>),         \
                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);       \
             if (e != hipSuccess) return e;                                                                  \
-            configured[RR] = lds;                                                                           \
         }                                                                                                   \
         hipLaunchKernelGGL(conf_band_kernel<RR>, grid, block, lds, st, a);                                  \
         break;
-    switch (a.radius) { ADF_CB(1) ADF_CB(2) ADF_CB(3) ADF_CB(4) }
+    switch (a.radius) { ADF_CB(1) ADF_CB(2) ADF_CB(3) ADF_CB(4) ADF_CB(5) ADF_CB(6) ADF_CB(7) ADF_CB(8) }
 #undef ADF_CB
     return hipGetLastError();
 }

@@ -45,15 +45,24 @@ __global__ void __launch_bounds__(64, (M > ADF_H_TWO_WAVE_MAX && R > 1) ? 1 : 2)
         const float4* sC = reinterpret_cast<const float4*>(a.C + off);
         // PAIR: t0 / t1 hold the first / second half of the interleaved row instead of U0 / U1
         const float4* s0 = reinterpret_cast<const float4*>(a.U0 + offU);
-        // fused inputs (the launcher guarantees 16 / 8 byte alignment and len % 4 == 0)
-        const float4* sF = nullptr; const short4* sD = nullptr;
+        // fused inputs (the launcher guarantees a 16-byte aligned conf row start and len >= 4)
+        const float4* sF = nullptr; const char* sD = nullptr;
         if (FUSED) {
             sF = reinterpret_cast<const float4*>(a.conf_in + (size_t)blockIdx.y * a.conf_frame +
                                                  (size_t)(a.conf_y0 + blockIdx.x) * a.conf_pitch + a.conf_x0);
-            sD = reinterpret_cast<const short4*>(reinterpret_cast<const char*>(a.dl_in) + (ptrdiff_t)blockIdx.y * a.dl_pair_stride +
-                                                 (ptrdiff_t)(a.dl_y0 + blockIdx.x) * a.dl_stride + (ptrdiff_t)a.dl_x0 * 2);
+            sD = reinterpret_cast<const char*>(a.dl_in) + (ptrdiff_t)blockIdx.y * a.dl_pair_stride +
+                 (ptrdiff_t)(a.dl_y0 + blockIdx.x) * a.dl_stride + (ptrdiff_t)a.dl_x0 * 2;
         }
-        const int nfused = a.len >> 2;
+        // fused: the row is ceil(len/4) vectors; conf (the library's own plane, Geom::cx0 / cpitch) is always 16-byte
+        // aligned, dL is the caller's and only 2-byte aligned for an odd ROI x (8-byte loads at any even address).
+        // A ROI width that is not a multiple of 4 ends in a partial vector: its dL load is moved back so that it
+        // ends with the row (never past the caller's buffer) and shifted into place afterwards, its conf elements
+        // past the row are cleared -- both in the second loop, behind one wave-uniform branch, so that no loaded
+        // value is touched while loads are still being issued.
+        const int nfull = a.len >> 2, rem = a.len & 3;
+        const int nfused = nfull + (rem ? 1 : 0);
+        const unsigned dl_last = (unsigned)a.len * 2u - 8u;      // byte offset of the last whole vector (len >= 4)
+        typedef short v4s_u __attribute__((ext_vector_type(4), aligned(2)));
         short4 draw[FUSED ? M / 4 : 1];                          // fused: the row of the left disparity map
         // (an explicit branch per load: "cond ? *p : zero" would make the compiler select between
         // addresses and park the zero in scratch memory)
@@ -64,13 +73,13 @@ __global__ void __launch_bounds__(64, (M > ADF_H_TWO_WAVE_MAX && R > 1) ? 1 : 2)
             if (FUSED) draw[k] = make_short4(0, 0, 0, 0);
             if (FUSED) {
                 typedef float v4f __attribute__((ext_vector_type(4)));
-                typedef short v4s __attribute__((ext_vector_type(4)));
                 if (idx < nvec) { const v4f q = __builtin_nontemporal_load(reinterpret_cast<const v4f*>(sC) + idx); tC[k] = make_float4(q.x, q.y, q.z, q.w); }
                 // loads only: the products conf*float(dL) wait for the second loop, or every iteration would
                 // wait for its own loads before the next one's are issued (14 memory latencies per row)
                 if (idx < nfused) {
                     const v4f cq = __builtin_nontemporal_load(reinterpret_cast<const v4f*>(sF) + idx);
-                    const v4s dq = __builtin_nontemporal_load(reinterpret_cast<const v4s*>(sD) + idx);
+                    const unsigned doff = min((unsigned)idx * 8u, dl_last);
+                    const v4s_u dq = __builtin_nontemporal_load(reinterpret_cast<const v4s_u*>(sD + doff));
                     t1[k] = make_float4(cq.x, cq.y, cq.z, cq.w);
                     draw[k] = make_short4(dq.x, dq.y, dq.z, dq.w);
                 }
@@ -83,9 +92,21 @@ __global__ void __launch_bounds__(64, (M > ADF_H_TWO_WAVE_MAX && R > 1) ? 1 : 2)
             }
         }
         if (FUSED) {                                             // U1 = conf, U0 = conf * float(dL)  (DF.cpp:288-290)
+            const int ktail = rem ? (nfull >> 6) : -1;           // wave-uniform: the one k that holds the partial vector
 #pragma unroll
-            for (int k = 0; k < M / 4; k++)
+            for (int k = 0; k < M / 4; k++) {
+                if (k == ktail && lane == (nfull & 63)) {        // elements rem..3 lie past the row
+                    const int sh = 16 * (4 - rem);
+                    unsigned long long w = (unsigned long long)(unsigned short)draw[k].x | ((unsigned long long)(unsigned short)draw[k].y << 16) |
+                                           ((unsigned long long)(unsigned short)draw[k].z << 32) | ((unsigned long long)(unsigned short)draw[k].w << 48);
+                    w >>= sh;
+                    draw[k] = make_short4((short)(w & 0xffff), (short)((w >> 16) & 0xffff), (short)((w >> 32) & 0xffff), (short)(w >> 48));
+                    if (rem < 2) t1[k].y = 0.0f;
+                    if (rem < 3) t1[k].z = 0.0f;
+                    t1[k].w = 0.0f;
+                }
                 t0[k] = make_float4(t1[k].x * (float)draw[k].x, t1[k].y * (float)draw[k].y, t1[k].z * (float)draw[k].z, t1[k].w * (float)draw[k].w);
+            }
         }
     }
     // columns [len, pitch) of every plane are zero by construction (the host zeroes the workspace
@@ -208,15 +229,16 @@ hipError_t launch_h(const WavePassArgs& a, int n_rhs, int n_pairs, hipStream_t s
 
 int wave_max_row_len() { return 64 * 64; }
 
-// The fused first pass reads conf as float4 and dL as short4: everything must be 16 / 8 byte aligned
-// and the row length a multiple of 4 (otherwise the caller materialises U0/U1 with the prologue).
+// The fused first pass reads conf as float4s -- the confidence plane is the library's own and laid out so that the ROI
+// row starts 16-byte aligned whatever the ROI is (Geom::cx0 / cpitch) -- and dL, the caller's map, in 8-byte pieces at
+// any 2-byte aligned address (round 3: any ROI x / width, any even stride).  Rows shorter than one vector go through
+// the prologue kernels instead.
 bool wave_hpass_can_fuse(const WavePassArgs& a)
 {
     if (!a.conf_in || !a.dl_in) return false;
-    if (a.len % 4 != 0 || a.conf_pitch % 4 != 0 || a.conf_x0 % 4 != 0 || a.conf_frame % 4 != 0) return false;
+    if (a.len < 4 || a.conf_pitch % 4 != 0 || a.conf_x0 % 4 != 0 || a.conf_frame % 4 != 0) return false;
     if ((reinterpret_cast<uintptr_t>(a.conf_in) & 15u) != 0) return false;
-    if (a.dl_x0 % 4 != 0 || a.dl_stride % 8 != 0 || a.dl_pair_stride % 8 != 0) return false;
-    if ((reinterpret_cast<uintptr_t>(a.dl_in) & 7u) != 0) return false;
+    if (a.dl_stride % 2 != 0 || a.dl_pair_stride % 2 != 0 || (reinterpret_cast<uintptr_t>(a.dl_in) & 1u) != 0) return false;
     return true;
 }
 

@@ -23,7 +23,7 @@ import math
 import numpy as np
 
 from . import _lib
-from ._lib import AdfError, Rect, SOLVER_EXACT, SOLVER_WAVE  # noqa: F401  (re-exported)
+from ._lib import AdfError, PATH_CONF_BAND, PATH_FUSED_FIRST_PASS, Rect, SOLVER_EXACT, SOLVER_WAVE  # noqa: F401  (re-exported)
 
 try:  # torch is optional plumbing: device memory and streams only
     import torch
@@ -190,6 +190,10 @@ class DisparityWLSFilter(DisparityFilter):
 
     def getLastSolver(self):
         return self._geti(_lib.lib().adf_wls_get_last_solver)
+
+    def getLastPath(self):
+        """PATH_* bits of the last filter call: which kernels its confidence stage took (introspection only)."""
+        return self._geti(_lib.lib().adf_wls_get_last_path)
 
     def enableProfiling(self, on=True):
         """Bracket every kernel launch with HIP events on the caller's stream (measurement hook)."""

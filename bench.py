@@ -59,7 +59,17 @@ def parse_args(argv=None):
                     help="pairs of the extra views -> matcher -> filter leg (SURVEY 8f N4; N=1 only, 0 = skip)")
     ap.add_argument("--dry-run", action="store_true",
                     help="launcher / rendezvous rehearsal without a GPU: gloo, no filter call, value 0 (tests)")
-    ap.add_argument("--launch-timeout", type=float, default=1500.0, help="self-launch: seconds before workers are stopped")
+    ap.add_argument("--roi", default="config",
+                    help="ROI of the filter call: 'config' (the BASELINE config's SGBM-factory ROI), 'bm' (what "
+                         "createDisparityWLSFilter derives from the sample's StereoBM, block 15: x = numDisparities + 7, "
+                         "y = 7, radius 5 -- DF.cpp:401-402), or x,y,w,h")
+    ap.add_argument("--radius", type=int, default=None, help="depth-discontinuity radius (default: the ROI choice's)")
+    ap.add_argument("--rccl-legs", choices=["auto", "off"], default="auto",
+                    help="N>1 with --distribution local: after the timed region also run the batch scatter / gather and "
+                         "the pipelined scatter -> filter -> gather leg over RCCL (never part of `value`)")
+    ap.add_argument("--launch-timeout", type=float, default=900.0,
+                    help="self-launch: seconds before workers are stopped (below the driver's own limit, so that a hung "
+                         "rendezvous is diagnosed here)")
     return ap.parse_args(argv)
 
 
@@ -166,9 +176,13 @@ def cpu_baseline(view, dl, dr, roi, radius, seconds):
     }
 
 
-def views_to_filtered(xi, view, roi, radius, n, num_disp, block, matcher="bm"):
+def views_to_filtered(xi, view, n, num_disp, block, matcher="bm", check=True):
     """Extra leg, outside the timed region and not part of `value`: a device matcher (both views) feeding the
-    filter, all stages on torch's stream, inputs resident."""
+    filter, all stages on torch's stream, inputs resident.
+
+    check: pair 0 against the oracle's pipeline -- the matcher's maps on the top rows of the frame (a block / 3-way
+    semi-global match of row y reads no row below y + blockSize/2 + 2, so the oracle runs on a crop and finishes in
+    seconds), then the filter of the device maps against the oracle's filter of the same maps on the whole frame."""
     import torch
     left = view[:n, :, :, 0].contiguous() if view.dim() == 4 else view[:n].contiguous()
     right = torch.roll(left, -min(num_disp // 3, 60), 2).contiguous()
@@ -195,11 +209,40 @@ def views_to_filtered(xi, view, roi, radius, n, num_disp, block, matcher="bm"):
         wls.filter(dl, view[:n], out, dr)
         ev[2].record()
     torch.cuda.synchronize()
-    return {"matcher": matcher, "pairs": n, "num_disparities": num_disp, "block_size": block, "roi": list(wls.getROI()),
-            "matcher_ms_per_pair": round(ev[0].elapsed_time(ev[1]) / n, 4),
-            "filter_ms_per_pair": round(ev[1].elapsed_time(ev[2]) / n, 4),
-            "Mpixels_per_s": round(n * H * W / (ev[0].elapsed_time(ev[2]) * 1e-3) / 1e6, 1),
-            "note": "left + right view matcher then the filter, each one call for the batch; not part of `value`"}
+    fl = wls.getLastPath()
+    res = {"matcher": matcher, "pairs": n, "num_disparities": num_disp, "block_size": block, "roi": list(wls.getROI()),
+           "radius": wls.getDepthDiscontinuityRadius(),
+           "path": {"conf_band_kernel": bool(fl & xi.PATH_CONF_BAND), "fused_first_row_pass": bool(fl & xi.PATH_FUSED_FIRST_PASS)},
+           "matcher_ms_per_pair": round(ev[0].elapsed_time(ev[1]) / n, 4),
+           "filter_ms_per_pair": round(ev[1].elapsed_time(ev[2]) / n, 4),
+           "Mpixels_per_s": round(n * H * W / (ev[0].elapsed_time(ev[2]) * 1e-3) / 1e6, 1),
+           "note": "left + right view matcher then the filter, each one call for the batch; not part of `value`"}
+    if check:
+        import numpy as np
+        import oracle
+        rows, crop = min(64, H), min(H, 96)
+        L, R = left[0, :crop].cpu().numpy(), right[0, :crop].cpu().numpy()
+        if matcher == "sgbm":
+            el = oracle.sgbm_compute(L, R, num_disp, block, 0, 24 * block * block, 96 * block * block, lm.getPreFilterCap(), 0)
+            er = oracle.sgbm_compute(R, L, num_disp, block, -num_disp + 1, 24 * block * block, 96 * block * block, rm.getPreFilterCap(), 0)
+        else:
+            el = oracle.bm_compute(L, R, num_disp, block, 0)
+            er = oracle.bm_compute(R, L, num_disp, block, -num_disp + 1)
+        gl, gr = dl[0].cpu().numpy(), dr[0].cpu().numpy()
+        maps_ok = bool(np.array_equal(gl[:rows], el[:rows]) and np.array_equal(gr[:rows], er[:rows]))
+        p = oracle.default_params(sigma_color=1.5, disc_radius=wls.getDepthDiscontinuityRadius(),
+                                  threads=len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else 8)
+        p.lambda_ = 8000.0
+        exp, exp_conf = oracle.wls_filter(gl, view[0].cpu().numpy(), gr, wls.getROI(), p)
+        diff = np.abs(out[0].cpu().numpy().astype(np.int64) - exp)
+        conf_ok = bool(np.array_equal(wls.getConfidenceMap(0).cpu().numpy(), exp_conf))
+        res["checked"] = bool(maps_ok and conf_ok and diff.max() <= 1 and diff.mean() <= 1 / 256)
+        res["check"] = {"pair": 0, "matcher_maps_bit_exact_rows": [0, rows] if maps_ok else False, "confidence_bit_exact": conf_ok,
+                        "disparity_max_abs_lsb": int(diff.max()), "disparity_mean_abs_lsb": float(diff.mean()),
+                        "valid_fraction_left_map": float((gl[:, num_disp:] >= 0).mean())}
+    else:
+        res["checked"] = None
+    return res
 
 
 def check_pairs(f, out, view, dl, dr, roi, radius, solver, which, threads):
@@ -269,6 +312,20 @@ def worker(args):
 
     cfg = synthetic.CONFIGS[args.config]
     W, H, roi, ch, radius = cfg["W"], cfg["H"], cfg["roi"], cfg["channels"], cfg["radius"]
+    roi_kind = args.roi
+    if args.roi == "bm":
+        # createDisparityWLSFilter on a StereoBM with the sample's full-size block 15 (samples/disparity_filtering.cpp:71,
+        # DF.cpp:401-402): ROI = (minD + numD + wsize/2, wsize/2, ...), radius ceil(0.33 * wsize)
+        nd, half = roi[0], 7
+        roi = (nd + half, half, W - nd - 2 * half, H - 2 * half)
+        radius = 5
+    elif args.roi != "config":
+        roi = tuple(int(v) for v in args.roi.split(","))
+        if len(roi) != 4 or roi[0] < 0 or roi[1] < 0 or roi[2] <= 0 or roi[3] <= 0 or roi[0] + roi[2] > W or roi[1] + roi[3] > H:
+            raise SystemExit("--roi x,y,w,h must lie inside the %dx%d frame" % (W, H))
+        roi_kind = "custom"
+    if args.radius is not None:
+        radius = args.radius
     pairs = args.pairs
     n_total = pairs * world
     vshape = (H, W, ch) if ch > 1 else (H, W)
@@ -380,12 +437,186 @@ def worker(args):
     if checked is not None:
         per_rank = parallel.gather_objects(checked) if world > 1 else [checked]
         checked_all = [dict(c, rank=r) for r, lst in enumerate(per_rank) for c in (lst or [])]
+    # who ran where: one record per rank, so that N ranks on N DISTINCT devices is visible in the line itself
+    ident = device_identity(torch, dev, dry, rank, local_rank)
+    ranks_info = parallel.gather_objects(ident) if world > 1 else [ident]
+    path = None
+    if f is not None:
+        fl = f.getLastPath()
+        path = {"conf_band_kernel": bool(fl & adf.PATH_CONF_BAND), "fused_first_row_pass": bool(fl & adf.PATH_FUSED_FIRST_PASS)}
 
-    if rank != 0:
-        if world > 1:
-            dist.destroy_process_group()
-        return
+    line = None
+    if rank == 0:
+        line = build_line(args, dry, world, backend, n_total, pairs, W, H, ch, roi, roi_kind, radius, elapsed, per_rank_ms,
+                          prof, checked_all, checksum, ranks_info, path, scatter_ms, gather_ms, pipelined,
+                          None if f is None else round(f.workspaceBytes() / 1e9, 2))
 
+    def emit():
+        if line is not None:
+            json_out.write(json.dumps(line) + "\n")
+            json_out.flush()
+
+    # ---- extra legs.  None of them is part of `value`, none may cost the line: every one runs inside try/except, and
+    # at N > 1 -- where a stuck transfer would hang all ranks -- under a watchdog that prints the line as it stands
+    # and ends every rank with status 0.
+    watchdog = None
+    if world > 1:
+        import threading
+
+        def bail():
+            if line is not None:
+                line.setdefault("rccl_legs", {})
+                if isinstance(line["rccl_legs"], dict):
+                    line["rccl_legs"]["watchdog"] = "extra legs did not finish in %.0f s: line printed without them" % limit
+            emit()
+            sys.stderr.write("bench: rank %d: extra-leg watchdog fired\n" % rank)
+            sys.stderr.flush()
+            os._exit(0)
+        limit = 240.0 + max(0.0, args.cpu_seconds) * 2
+        watchdog = threading.Timer(limit, bail)
+        watchdog.daemon = True
+        watchdog.start()
+
+    if world > 1 and args.distribution == "local" and args.rccl_legs == "auto":
+        legs = None
+        try:
+            if dry:
+                # rehearsal with CPU tensors over gloo: same code path, tiny items, "filter" = a copy with a twist
+                item = (4, 4)
+                vals = lambda r: (10 * r, 11 * r + 1, 0)              # a + b - v = r + 1 = what this rank's `out` holds
+                mine = [torch.full((pairs,) + item, v, dtype=torch.int16) for v in vals(rank)]
+                legs = rccl_legs(parallel, torch, dist, rank, world, dev, coll_dev, n_total, pairs, [item] * 3, [torch.int16] * 3,
+                                 item, torch.int16, mine, out,
+                                 lambda r: [torch.full((pairs,) + item, v, dtype=torch.int16) for v in vals(r)],
+                                 lambda v, a, b, o: o.copy_(a + b - v), args.sub_batches, elapsed / args.steps * 1e3, lambda: None)
+            elif backend != "nccl":
+                legs = {"skipped": "backend %s cannot move device tensors" % backend}
+            else:
+                legs = rccl_legs(parallel, torch, dist, rank, world, dev, coll_dev, n_total, pairs,
+                                 [vshape, (H, W), (H, W)], [torch.uint8, torch.int16, torch.int16], (H, W), torch.int16,
+                                 [view, dl, dr], out,
+                                 lambda r: synthetic.make_artificial_batch_torch(pairs, W, H, ch, base_seed + r * pairs,
+                                                                                 cfg["rect_disparity"], dev),
+                                 lambda v, a, b, o: f.filter(a, v, o, b, roi), args.sub_batches, elapsed / args.steps * 1e3, sync)
+        except Exception as e:                               # (a failure on one rank only would leave the others waiting:
+            legs = {"error": "%s: %s" % (type(e).__name__, e)}    #  the watchdog ends that)
+        if line is not None:
+            line["rccl_legs"] = legs
+
+    if rank == 0 and args.cpu_seconds > 0 and not dry:
+        try:
+            ncpu = min(pairs, 2)
+            cpu = cpu_baseline(view[:ncpu].cpu().numpy(), dl[:ncpu].cpu().numpy(), dr[:ncpu].cpu().numpy(), roi, radius,
+                               args.cpu_seconds)
+            line["cpu_baseline"] = cpu
+            line["speedup_vs_cpu"] = round(line["value"] / cpu["value"], 1)
+        except Exception as e:
+            line["cpu_baseline"] = None
+            line["cpu_baseline_error"] = str(e)
+    if world > 1:
+        dist.barrier()                                       # the other ranks wait here while rank 0 times the CPU port
+
+    if rank == 0 and world == 1 and args.matcher_pairs > 0 and not dry:
+        nd = max(16, (cfg["roi"][0] + 15) // 16 * 16)       # the config's ROI x is its numDisparities
+        pipeline = {}
+        for m, blk in (("bm", 15), ("sgbm", 3)):
+            try:
+                pipeline[m] = views_to_filtered(adf, view, min(args.matcher_pairs, pairs), min(nd, 256), blk, m, not args.no_check)
+            except Exception as e:                           # the extra leg must never cost the bench line
+                pipeline[m] = {"error": str(e)}
+        line["views_to_filtered"] = pipeline
+
+    if watchdog is not None:
+        watchdog.cancel()
+    emit()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def device_identity(torch, dev, dry, rank, local_rank):
+    """What a reader needs to see that N ranks ran on N distinct devices."""
+    info = {"rank": rank, "local_rank": local_rank, "host": socket.gethostname(), "pid": os.getpid()}
+    if dry:
+        info.update(device="cpu", name=None, uuid=None, pci_bus_id=None)
+        return info
+    props = torch.cuda.get_device_properties(dev)
+    info.update(device="cuda:%d" % dev.index, name=torch.cuda.get_device_name(dev),
+                uuid=str(getattr(props, "uuid", None)), multi_processor_count=getattr(props, "multi_processor_count", None),
+                total_memory_GB=round(props.total_memory / 1e9, 1))
+    pci = None
+    try:
+        from addingdisparityfiltering_amd import _lib
+        pci = _lib.device_pci_bus_id(dev.index)              # hipDeviceGetPCIBusId through the C-ABI
+    except Exception:
+        pci = None
+    if pci is None and hasattr(props, "pci_bus_id"):
+        pci = "%04x:%02x:%02x" % (getattr(props, "pci_domain_id", 0), props.pci_bus_id, getattr(props, "pci_device_id", 0))
+    info["pci_bus_id"] = pci
+    return info
+
+
+def rccl_legs(parallel, torch, dist, rank, world, dev, coll_dev, n_total, pairs, in_shapes, in_dtypes, out_shape, out_dtype,
+              mine, out, make_shard, process, n_sub, resident_ms, sync):
+    """The data-path exchange of SURVEY 8(e) over the process group (RCCL on a GPU node), run AFTER the timed region of a
+    `--distribution local` bench so that the first multi-GPU record exercises it: rank 0 builds the whole batch (every
+    rank's shard with that rank's seed), scatters it with point-to-point groups, every rank compares what arrived with the
+    shard it generated itself, the filtered maps are gathered on rank 0 and compared with the all-reduced checksum, and
+    the pipelined scatter -> filter -> gather leg runs on the same data."""
+    full, ok_build = None, 1.0
+    if rank == 0:
+        try:
+            shards = [mine if r == 0 else list(make_shard(r)) for r in range(world)]
+            full = [torch.cat([sh[k] for sh in shards]) for k in range(len(mine))]
+            del shards
+        except Exception as e:                               # e.g. out of memory: agree on skipping, never a half-run exchange
+            sys.stderr.write("bench: rank 0 could not build the whole batch: %s\n" % e)
+            full, ok_build = None, 0.0
+    if parallel.min_over_ranks(ok_build, coll_dev) < 0.5:
+        return {"skipped": "rank 0 could not build the whole batch"}
+    sync(); dist.barrier()
+    t0 = time.perf_counter()
+    got = [parallel.scatter_batch(None if full is None else full[k], n_total, in_shapes[k], in_dtypes[k], dev)
+           for k in range(len(mine))]
+    sync(); dist.barrier()
+    scatter_ms = (time.perf_counter() - t0) * 1e3
+    same = all(bool(torch.equal(g, m)) for g, m in zip(got, mine))
+    scatter_ok = parallel.min_over_ranks(1.0 if same else 0.0, coll_dev) > 0.5
+    del got
+    sync(); dist.barrier()
+    t1 = time.perf_counter()
+    full_out = parallel.gather_batch(out, n_total)
+    sync(); dist.barrier()
+    gather_ms = (time.perf_counter() - t1) * 1e3
+    total = parallel.sum_over_ranks(float(out.to(torch.int64).sum().item()), coll_dev)
+    gather_ok = None
+    if rank == 0:
+        gather_ok = float(full_out.to(torch.int64).sum().item()) == total
+    del full_out
+    pipelined, piped_out = parallel.pipelined_scatter_filter_gather(full, n_total, in_shapes, in_dtypes, out_shape, out_dtype,
+                                                                    dev, process, n_sub)
+    piped_ok = None
+    if rank == 0:
+        piped_ok = float(piped_out.to(torch.int64).sum().item()) == total
+    del piped_out, full
+    in_bytes = sum(int(torch.empty((), dtype=d).element_size()) * int(torch.Size(sh).numel()) for sh, d in zip(in_shapes, in_dtypes))
+    out_bytes = int(torch.empty((), dtype=out_dtype).element_size()) * int(torch.Size(out_shape).numel())
+    moved_in, moved_out = in_bytes * pairs * (world - 1), out_bytes * pairs * (world - 1)
+    pipelined["resident_compute_ms"] = round(resident_ms, 3)
+    pipelined["exposed_transfer_ms"] = round(pipelined["total_ms"] - resident_ms, 3)
+    pipelined["hidden_transfer_ms"] = round(max(0.0, scatter_ms + gather_ms - pipelined["exposed_transfer_ms"]), 3)
+    pipelined["output_checksum_matches"] = piped_ok
+    return {"backend": dist.get_backend(), "world_size": dist.get_world_size(),
+            "scatter_ms": round(scatter_ms, 2), "scatter_GBs_from_root": round(moved_in / max(scatter_ms, 1e-9) / 1e6, 1),
+            "scattered_shards_equal_locally_generated": scatter_ok,
+            "gather_ms": round(gather_ms, 2), "gather_GBs_into_root": round(moved_out / max(gather_ms, 1e-9) / 1e6, 1),
+            "gathered_checksum_matches": gather_ok,
+            "pipelined_scatter_filter_gather": pipelined,
+            "note": "after the timed region, never part of `value`: root <-> peers point-to-point groups (7 xGMI links at N = 8)"}
+
+
+def build_line(args, dry, world, backend, n_total, pairs, W, H, ch, roi, roi_kind, radius, elapsed, per_rank_ms, prof,
+               checked_all, checksum, ranks_info, path, scatter_ms, gather_ms, pipelined, workspace_gb):
+    """Everything of the JSON line that is known when the timed region and the pair checks are done (rank 0)."""
     mpx = 0.0 if dry else n_total * W * H * args.steps / elapsed / 1e6
     P = roi[2] * roi[3]
     alg_per_launch = 20.0 * P * pairs          # (4 + 8R) bytes per ROI pixel, R = 2 (SURVEY 8d)
@@ -423,6 +654,10 @@ def worker(args):
             tj = json.load(open(tpath))
             t = tj.get("%s_cfg%d" % (args.solver, args.config), {})
             per_pair = t.get(names[dom_classes[0]], {}).get("bytes_per_pair")
+            # the figure was collected on the config's own ROI: scale by the ROI area of this run
+            cfg_roi = t.get("_roi")
+            if per_pair is not None and cfg_roi and list(cfg_roi) != list(roi):
+                per_pair = per_pair * P / float(cfg_roi[2] * cfg_roi[3])
             traffic = None if per_pair is None else per_pair * pairs
             traffic_src = {"file": "profiles/pmc_traffic.json", "collected": tj.get("_collected"),
                            "kernel_sources_sha16": tj.get("_kernel_sources_sha16"),
@@ -446,55 +681,37 @@ def worker(args):
                    "alg_GBs": round(v["alg_bytes"] / max(v["total_ms"], 1e-9) / 1e6, 1),
                    "moved_GBs": round(v["moved_bytes"] / max(v["total_ms"], 1e-9) / 1e6, 1)} for k, v in prof.items()}
 
-    cpu = None
-    if world == 1 and args.cpu_seconds > 0 and not dry:
-        ncpu = min(pairs, 2)
-        cpu = cpu_baseline(view[:ncpu].cpu().numpy(), dl[:ncpu].cpu().numpy(), dr[:ncpu].cpu().numpy(), roi, radius,
-                           args.cpu_seconds)
-
-    pipeline = None
-    if world == 1 and args.matcher_pairs > 0 and not dry:
-        nd = max(16, (roi[0] + 15) // 16 * 16)               # the config's ROI x is its numDisparities
-        pipeline = {}
-        for m, blk in (("bm", 15), ("sgbm", 3)):
-            if m == "sgbm" and not hasattr(adf.StereoSGBM, "MODE_SGBM_3WAY"):
-                continue
-            try:
-                pipeline[m] = views_to_filtered(adf, view, roi, radius, min(args.matcher_pairs, pairs), min(nd, 256), blk, m)
-            except Exception as e:                           # the extra leg must never cost the bench line
-                pipeline[m] = {"error": str(e)}
-
     F = W * H
     b_alg_pair = 10.0 * F + (ch + 8 + 120) * P  # I/O + weights + 6 passes
+    pcis = [r.get("pci_bus_id") or r.get("uuid") for r in ranks_info]
     line = {
         "metric": "filtered Mpixels/s (+ achieved HBM GB/s) on 4K disparity, 1/2/4/8 GPUs vs CPU ref",
         "value": round(mpx, 2), "unit": "Mpixels/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": "BASELINE config %d: %d pairs/GPU of %dx%d, ROI %s, 8UC%d guide, lambda 8000 sigma 1.5, "
-                               "3 FGS iterations, LRC confidence on" % (args.config, pairs, W, H, list(roi), ch),
-                   "pairs_per_gpu": pairs, "total_pairs": n_total, "solver": args.solver,
-                   "distribution": args.distribution if world > 1 else "resident",
+        "config": {"workload": "BASELINE config %d: %d pairs/GPU of %dx%d, ROI %s (%s), depth-discontinuity radius %d, 8UC%d "
+                               "guide, lambda 8000 sigma 1.5, 3 FGS iterations, LRC confidence on"
+                               % (args.config, pairs, W, H, list(roi), roi_kind, radius, ch),
+                   "pairs_per_gpu": pairs, "total_pairs": n_total, "solver": args.solver, "roi": list(roi), "roi_kind": roi_kind,
+                   "radius": radius, "distribution": args.distribution if world > 1 else "resident",
                    "parallelism": "batch-sharded x%d" % world},
-        "roofline": roofline, "cpu_baseline": cpu,
+        "roofline": roofline, "cpu_baseline": None,
         "whole_call_alg_GBs": round(b_alg_pair * n_total * args.steps / elapsed / 1e9, 1),
-        "kernels": kernels, "checked": checked_all, "checksum": checksum,
+        "kernels": kernels, "path": path, "checked": checked_all, "checksum": checksum,
         "world_size": world, "backend": backend if world > 1 else None, "per_rank_ms_per_step": per_rank_ms,
+        "ranks": ranks_info,
+        "distinct_devices": None if dry else (len(set(pcis)) == world and None not in pcis),
         "launcher": "self" if os.environ.get("ADF_BENCH_WORKER") else ("torchrun" if world > 1 else "single"),
         "scatter_ms": None if scatter_ms is None else round(scatter_ms, 2),
         "gather_ms": None if gather_ms is None else round(gather_ms, 2),
         "pipelined_scatter_filter_gather": pipelined,
-        "workspace_GB": None if f is None else round(f.workspaceBytes() / 1e9, 2),
-        "views_to_filtered": pipeline,
+        "rccl_legs": None,
+        "workspace_GB": workspace_gb,
+        "views_to_filtered": None,
     }
     if dry:
         line["dry_run"] = True
-    if cpu:
-        line["speedup_vs_cpu"] = round(mpx / cpu["value"], 1)
-    json_out.write(json.dumps(line) + "\n")
-    json_out.flush()
-    if world > 1:
-        dist.destroy_process_group()
+    return line
 
 
 def _kernel_sources_sha16():

@@ -75,6 +75,9 @@ int adf_version(void);
 const char* adf_last_error(void);
 /* Number of visible HIP devices (0 when none); never fails. */
 int adf_device_count(void);
+/* PCI bus id ("0000:c1:00.0") of HIP device `device` into buf (at least 16 bytes): lets a multi-process harness show
+ * that its ranks sit on distinct devices.  No counterpart in the reference (it has no device layer). */
+int adf_device_pci_bus_id(int device, char* buf, int len);
 
 /* ---------------- DisparityWLSFilter ---------------- */
 
@@ -107,6 +110,13 @@ int adf_wls_get_solver(const adf_wls_t* h, int* solver);
 /* Solver the last filter call actually ran: ADF_SOLVER_WAVE covers ROIs up to 4096 x 2176; larger
  * ones fall back to ADF_SOLVER_EXACT. */
 int adf_wls_get_last_solver(const adf_wls_t* h, int* solver);
+/* Which kernels the confidence stage of the last filter call took (introspection for tests and benchmarks; the
+ * results do not depend on it): ADF_PATH_CONF_BAND = computeConfidenceMap (DF.cpp:197-210) ran as the one-sweep band
+ * kernel (depth-discontinuity radius 1..8), ADF_PATH_FUSED_FIRST_PASS = the first row pass formed conf*disp itself
+ * (DF.cpp:288-290) instead of reading planes a prologue kernel wrote. */
+#define ADF_PATH_CONF_BAND 1
+#define ADF_PATH_FUSED_FIRST_PASS 2
+int adf_wls_get_last_path(const adf_wls_t* h, int* path_flags);
 
 /* DisparityFilter::filter (DF.hpp:75, DF.cpp:219-298) on a batch of n_pairs
  * independent, equally sized stereo pairs laid out `*_pair_stride` bytes apart

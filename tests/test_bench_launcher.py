@@ -32,6 +32,26 @@ def test_self_launch_two_ranks_one_line():
     assert d["config"]["total_pairs"] == 4 and d["config"]["parallelism"] == "batch-sharded x2"
     # checksum all-reduce: rank r contributes pairs * 16 * (r + 1)
     assert d["checksum"] == 2 * 16 * (1 + 2)
+    # round 3: who ran where, per rank, and the data-path exchange (scatter / gather / pipelined leg) runs by default at
+    # N > 1 after the timed region -- here over gloo with CPU tensors, on a GPU node over RCCL
+    assert [r["rank"] for r in d["ranks"]] == [0, 1] and len({r["pid"] for r in d["ranks"]}) == 2
+    assert all(set(("device", "name", "uuid", "pci_bus_id", "host", "local_rank")) <= set(r) for r in d["ranks"])
+    assert d["backend"] == "gloo" and "distinct_devices" in d
+    legs = d["rccl_legs"]
+    assert legs["backend"] == "gloo" and legs["world_size"] == 2
+    assert legs["scattered_shards_equal_locally_generated"] is True and legs["gathered_checksum_matches"] is True
+    assert legs["scatter_ms"] > 0 and legs["gather_ms"] > 0
+    pl = legs["pipelined_scatter_filter_gather"]
+    assert pl["sub_batches"] >= 1 and pl["total_ms"] > 0 and pl["output_checksum_matches"] is True
+    assert "cpu_baseline" in d and "path" in d
+
+
+def test_rccl_legs_can_be_switched_off():
+    p = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--dry-run", "--steps", "1", "--warmup", "0", "--rccl-legs", "off"],
+                       cwd=ROOT, env=_clean_env(), capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stderr[-3000:]
+    d = json.loads(p.stdout.strip())
+    assert d["rccl_legs"] is None and d["n_gpus"] == 2
 
 
 def test_already_under_a_launcher_is_a_worker():

@@ -34,6 +34,10 @@ def _check(adf, oracle, W, H, roi, radius, kind, seed, thresh=24):
     f.setDepthDiscontinuityRadius(radius); f.setLRCthresh(thresh)
     f.filter(dl, view, None, dr, roi)
     assert f.getLastSolver() == adf.SOLVER_WAVE
+    # the kernels under test really ran: the one-sweep confidence kernel and the first row pass that reads its map
+    # (ROIs with no more rows than the radius, or narrower than 8 columns, take the column-walking kernels instead)
+    band = roi[3] > radius and roi[2] >= 8 and roi[2] > radius
+    assert f.getLastPath() == (adf.PATH_CONF_BAND if band else 0) | adf.PATH_FUSED_FIRST_PASS, f.getLastPath()
     got = f.getConfidenceMap()
     assert np.array_equal(got, exp), (W, H, roi, radius, kind, int((got != exp).sum()))
     return f
@@ -46,6 +50,29 @@ def test_widths_and_radii(adf, oracle, rw, radius):
     H = 37
     W = rw + 8
     _check(adf, oracle, W, H, (4, 0, rw, H), radius, "scene", rw * 10 + radius)
+
+
+# Radius 5..8 (round 3): two halo lanes per side, 240 output columns per wave.  5 is createDisparityWLSFilterGeneric's
+# default and the StereoBM factory's value for its default block sizes (DF.cpp:155, 402); widths around the wave
+# boundaries, not multiples of 4, up to the widest row 16 waves cover.
+@pytest.mark.parametrize("rw", [9, 13, 236, 239, 240, 241, 244, 480, 483, 721, 1000, 2399, 2401, 3570, 3838, 3840])
+@pytest.mark.parametrize("radius", [5, 6, 7, 8])
+def test_widths_and_large_radii(adf, oracle, rw, radius):
+    H = 41
+    W = rw + 11
+    _check(adf, oracle, W, H, (7, 1, rw, H - 2), radius, "scene", rw * 10 + radius)
+
+
+@pytest.mark.parametrize("kind", ["wild", "wide"])
+@pytest.mark.parametrize("radius", [5, 8])
+def test_arbitrary_disparities_large_radii(adf, oracle, kind, radius):
+    _check(adf, oracle, 523, 70, (9, 3, 501, 60), radius, kind, 500 + radius)
+
+
+def test_bm_factory_geometry(adf, oracle):
+    """The ROI and radius createDisparityWLSFilter derives from the sample's full-size StereoBM (block 15, DF.cpp:401-402:
+    x = numDisparities + 7, radius ceil(0.33 * 15) = 5) on a 4K-wide strip: odd ROI x, width 3570 = 4*892 + 2."""
+    _check(adf, oracle, 3840, 64, (263, 7, 3570, 50), 5, "scene", 4242)
 
 
 @pytest.mark.parametrize("kind", ["wild", "wide", "scene"])
@@ -98,12 +125,17 @@ def test_band_kernel_equals_two_kernel_stage(adf, oracle):
     assert np.array_equal(outs[0][1], oracle.confidence(dl, dr, roi, 3, 24, threads=8))
 
 
-def _random_aligned_case(rng):
-    """Geometry the one-sweep kernel takes: frame width, ROI x and ROI width multiples of 4, radius 1..4."""
-    rw = 4 * int(rng.integers(2, 260)); rh = int(rng.integers(5, 140))
-    rx = 4 * int(rng.integers(0, 40)); ry = int(rng.integers(0, 9))
-    W = rx + rw + 4 * int(rng.integers(0, 30)); H = ry + rh + int(rng.integers(0, 9))
-    radius = int(rng.integers(1, 5))
+def _random_aligned_case(rng, unaligned=False):
+    """Geometry of round 2's fast path: frame width, ROI x and ROI width multiples of 4, radius 1..4 -- or (round 3)
+    anything: odd ROI x / width / frame width, radius 1..8."""
+    q = 1 if unaligned else 4
+    rw = q * int(rng.integers(2, 260) * (4 // q)) + (int(rng.integers(0, 4)) if unaligned else 0); rh = int(rng.integers(5, 140))
+    rx = q * int(rng.integers(0, 40) * (4 // q)) + (int(rng.integers(0, 4)) if unaligned else 0); ry = int(rng.integers(0, 9))
+    W = rx + rw + q * int(rng.integers(0, 30)); H = ry + rh + int(rng.integers(0, 9))
+    radius = int(rng.integers(1, 9 if unaligned else 5))
+    if unaligned:
+        rw = max(rw, 9)
+    W = max(W, rx + rw)
     if rh <= radius:
         rh = radius + 1; H = max(H, ry + rh)
     kind = str(rng.choice(["scene", "wide", "wild"]))
@@ -115,3 +147,45 @@ def test_random_aligned_geometries(adf, oracle, seed):
     rng = np.random.default_rng(7000 + seed)
     W, H, roi, radius, kind, thresh = _random_aligned_case(rng)
     _check(adf, oracle, W, H, roi, radius, kind, 7000 + seed, thresh)
+
+
+@pytest.mark.parametrize("seed", range(40))
+def test_random_unaligned_geometries(adf, oracle, seed):
+    """Round 3: any ROI x / width / frame width and radius 1..8 take the one-sweep kernel and the fused first pass."""
+    rng = np.random.default_rng(9000 + seed)
+    W, H, roi, radius, kind, thresh = _random_aligned_case(rng, unaligned=True)
+    _check(adf, oracle, W, H, roi, radius, kind, 9000 + seed, thresh)
+
+
+@pytest.mark.parametrize("rx,rw,W,off", [(263, 3570, 3840, 0), (1, 9, 11, 1), (3, 250, 256, 3), (5, 1003, 1011, 1), (2, 4, 8, 0), (7, 5, 13, 1)])
+def test_filtered_map_on_unaligned_rois(adf, oracle, rx, rw, W, off):
+    """The whole call on ROIs the first row pass could not fuse before round 3 (ROI x, width not multiples of 4; disparity
+    rows that start at an odd element of a wider device tensor, so the 8-byte loads of dL sit at 2-byte aligned
+    addresses): confidence bit-exact, filtered map within the reference's own bar of the oracle, exact solver
+    bit-exact, and the partial last vector of a row never leaks into the padding (same result as on a dense copy)."""
+    import torch
+    rng = np.random.default_rng(rx * 7 + rw)
+    H = 45; roi = (rx, 2, rw, H - 5); radius = 5 if rw > 8 else 2
+    dl, dr = _maps(rng, H, W, "scene")
+    view = rng.integers(0, 255, (H, W, 3), dtype=np.uint8)
+    p = oracle.default_params(threads=8, use_confidence=1, disc_radius=radius, sigma_color=1.5)
+    p.lambda_ = 8000.0
+    exp, exp_conf = oracle.wls_filter(dl, view, dr, roi, p)
+    wide_l = torch.zeros((H, W + 6), dtype=torch.int16, device="cuda"); wide_r = torch.zeros_like(wide_l)
+    wide_l[:, off:off + W] = torch.from_numpy(dl).cuda(); wide_r[:, off:off + W] = torch.from_numpy(dr).cuda()
+    tv = torch.from_numpy(view).cuda()
+    f = adf.createDisparityWLSFilterGeneric(True)
+    f.setLambda(8000.0); f.setSigmaColor(1.5); f.setDepthDiscontinuityRadius(radius)
+    for solver in (adf.SOLVER_WAVE, adf.SOLVER_EXACT):
+        f.setSolver(solver)
+        out = f.filter(wide_l[:, off:off + W], tv, None, wide_r[:, off:off + W], roi)
+        torch.cuda.synchronize()
+        assert np.array_equal(f.getConfidenceMap().cpu().numpy(), exp_conf)
+        d = np.abs(out.cpu().numpy().astype(np.int64) - exp.astype(np.int64))
+        if solver == adf.SOLVER_EXACT:
+            assert d.max() == 0
+        else:
+            assert f.getLastPath() == (adf.PATH_CONF_BAND if rw >= 8 else 0) | adf.PATH_FUSED_FIRST_PASS
+            assert d.max() <= 1 and d.mean() <= 1 / 256.0, (d.max(), d.mean())
+            dense = f.filter(torch.from_numpy(dl).cuda(), tv, None, torch.from_numpy(dr).cuda(), roi)
+            assert torch.equal(dense, out)
