@@ -577,25 +577,37 @@ __global__ void __launch_bounds__(64 * CB_MAX_WAVES) conf_band_kernel(ConfBandAr
 
 constexpr int OUT_ROWS = 16; // rows per block of outside_kernel
 
-__global__ void __launch_bounds__(NT) outside_kernel(OutsideArgs a)
+// Non-ROI pixels of the frame: the side columns of the ROI's rows (part A: W - rw columns x rh rows, blocks of NT
+// columns x OUT_ROWS rows) and the whole rows above / below the ROI (part B: (H - rh) x W pixels, a flat index in
+// blocks of NT * OUT_ROWS pixels).  blockIdx.x < nA: part A, else part B -- no block without work (round 3: the BM
+// factory's ROI has rows outside it, and a grid over the whole frame spent 0.49 ms per 64 x 4K step finding that out).
+__global__ void __launch_bounds__(NT) outside_kernel(OutsideArgs a, int nAx, int nA)
 {
-    // blockIdx.x walks the columns that can be outside the ROI: all W columns when some row lies
-    // outside the ROI's row range, else only the W - rw columns left and right of it
     const Geom& g = a.g;
-    const bool full_rows = g.ry > 0 || g.ry + g.rh < g.H;
-    const int t = blockIdx.x * NT + threadIdx.x;
-    for (int k = 0; k < OUT_ROWS; k++) {
-        const int i = blockIdx.y * OUT_ROWS + k;
-        if (i >= g.H) break;
-        const bool roi_row = i >= g.ry && i < g.ry + g.rh;
-        int j;
-        if (full_rows && !roi_row) j = t;
-        else { if (t >= g.W - g.rw) continue; j = t < g.rx ? t : t + g.rw; }
-        if (j >= g.W) continue;
-        if (a.out)
-            reinterpret_cast<int16_t*>(reinterpret_cast<char*>(a.out) + (ptrdiff_t)blockIdx.z * a.pair_stride +
-                                       (ptrdiff_t)i * a.stride)[j] = a.fill;
-        if (a.conf) a.conf[(size_t)blockIdx.z * g.cframe + (size_t)i * g.cpitch + g.cx0 + j] = 0.0f;
+    char* out = a.out ? reinterpret_cast<char*>(a.out) + (ptrdiff_t)blockIdx.z * a.pair_stride : nullptr;
+    float* conf = a.conf ? a.conf + (size_t)blockIdx.z * g.cframe + g.cx0 : nullptr;
+    if ((int)blockIdx.x < nA) {
+        const int bx = blockIdx.x % nAx, by = blockIdx.x / nAx;
+        const int t = bx * NT + threadIdx.x;
+        if (t >= g.W - g.rw) return;
+        const int j = t < g.rx ? t : t + g.rw;
+        const int i0 = g.ry + by * OUT_ROWS, i1 = min(i0 + OUT_ROWS, g.ry + g.rh);
+        for (int i = i0; i < i1; i++) {
+            if (out) reinterpret_cast<int16_t*>(out + (ptrdiff_t)i * a.stride)[j] = a.fill;
+            if (conf) conf[(size_t)i * g.cpitch + j] = 0.0f;
+        }
+    } else {
+        const size_t npix = (size_t)(g.H - g.rh) * g.W;
+        size_t p = (size_t)(blockIdx.x - nA) * (NT * OUT_ROWS) + threadIdx.x;
+#pragma unroll 4
+        for (int k = 0; k < OUT_ROWS; k++, p += NT) {
+            if (p >= npix) break;
+            int i = (int)(p / (size_t)g.W);
+            const int j = (int)(p - (size_t)i * g.W);
+            if (i >= g.ry) i += g.rh;                        // rows below the ROI
+            if (out) reinterpret_cast<int16_t*>(out + (ptrdiff_t)i * a.stride)[j] = a.fill;
+            if (conf) conf[(size_t)i * g.cpitch + j] = 0.0f;
+        }
     }
 }
 
@@ -867,11 +879,13 @@ hipError_t launch_conf_left(const ConfLeftArgs& a, int n_pairs, hipStream_t st)
 
 hipError_t launch_outside(const OutsideArgs& a, int n_pairs, hipStream_t st)
 {
-    const bool full_rows = a.g.ry > 0 || a.g.ry + a.g.rh < a.g.H;
-    const int cols = full_rows ? a.g.W : a.g.W - a.g.rw;
-    if (cols <= 0) return hipSuccess;
-    dim3 grid((cols + NT - 1) / NT, (a.g.H + OUT_ROWS - 1) / OUT_ROWS, n_pairs);
-    hipLaunchKernelGGL(outside_kernel, grid, dim3(NT), 0, st, a);
+    const int side = a.g.W - a.g.rw;
+    const int nAx = (side + NT - 1) / NT, nA = side > 0 ? nAx * ((a.g.rh + OUT_ROWS - 1) / OUT_ROWS) : 0;
+    const size_t npix = (size_t)(a.g.H - a.g.rh) * a.g.W;
+    const size_t nB = (npix + (size_t)NT * OUT_ROWS - 1) / ((size_t)NT * OUT_ROWS);
+    if (nA + nB == 0) return hipSuccess;
+    if (nA + nB > 0x7fffffffu) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(outside_kernel, dim3((unsigned)(nA + nB), 1, n_pairs), dim3(NT), 0, st, a, nAx > 0 ? nAx : 1, nA);
     return hipGetLastError();
 }
 

@@ -39,14 +39,118 @@ using namespace wave;
 constexpr int VT = 512;  // threads per strip
 constexpr int VC = 16;   // columns per strip
 
+// ---------------------------------------------------------------------------------------------
+// Whole-line loads by LDS-DMA (round 3; NOT the default: -DADF_V_GLDS=1 selects it).  Moving the pass's bytes alone
+// (tools/micro/vpattern.hip) this shape is 15 % faster than the register loads below, but in the pass every wave meets
+// the others at the barrier before the reduced system, so the strip is not done before its slowest wave's loads are:
+// A/B on the 64 x 4K step 4.25-4.29 ms (DMA) against 4.19-4.21 ms (register loads) for the two plain passes, and
+// the short columns of 1242 x 375 frames lose 8 % to the ring's LDS (profiles/r03_ab_glds.txt).
+// A thread owns (chunk, column pair), so loading straight into its registers
+// makes every wave instruction fetch 8 rows x 64 bytes at 8 bytes per lane ("fragment-shaped"): measured on the pass's
+// own layout (tools/micro/vpattern.hip, profiles/r03_vpattern.txt) that moves the pass's bytes at 4.5 TB/s, while
+// global_load_lds_dwordx4 instructions that fetch 8 WHOLE 128-byte lines each (16 bytes per lane, half as many
+// instructions, no register destination) into a small per-wave LDS ring, followed by 8-byte LDS reads into the same
+// registers, move them at 5.3 TB/s.  Items of a wave's load sequence, for its 8 chunks at once:
+//   line item i    row r0+i of the pair plane: [U0 x16 | U1 x16] = one line per chunk, lane (chunk j, piece p)
+//   weight item k  rows r0+2k, r0+2k+1 of the strip-major weights: 2 x 64 bytes per chunk, lane (j, row parity, piece)
+// in the order L0 L1 W0 L2 L3 W1 ..., 3M/2 items, VRING slots of 1 KiB in flight per wave.  The DMA is issued by
+// inline asm (M0 = LDS destination), so its waits are counted here by hand: item K is complete once at most
+// (items issued after K) operations are outstanding -- anything else the compiler has in flight is older or younger
+// than all of them and only makes the wait stronger.
+// ---------------------------------------------------------------------------------------------
+#ifndef ADF_V_GLDS
+#define ADF_V_GLDS 0   // 1: LDS-DMA whole-line loads (round-3 experiment, kept for A/B: the pass gains nothing, see below)
+#endif
+// (short columns leave room for two workgroups per CU: their rings stay small enough not to take that away)
+template <int M> struct VRing { static constexpr int ITEMS = 3 * M / 2, WANT = M >= 18 ? 12 : 4, SLOTS = ITEMS < WANT ? ITEMS : WANT; };
+
+template <int N> __device__ __forceinline__ void v_wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" :: "n"(N) : "memory"); }
+__device__ __forceinline__ void v_wait_lds() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+__device__ __forceinline__ void v_glds16(const void* gsrc, unsigned lds_dst)
+{
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+}
+
+struct VLoadCtx {
+    const char* bC; const char* b0;
+    unsigned lo, line_safe;        // byte offset of the NEXT line item's line / of row 0 of this strip (piece offset included)
+    unsigned wo, w_safe;           // byte offset of the NEXT weight item's row / of row 0 (row parity and piece included)
+    unsigned tile_b, r0, h, q;     // q = row parity this lane fetches in a weight item
+    unsigned ring;                 // LDS byte address of the wave's ring (SGPR)
+    unsigned rd;                   // this thread's read position inside a slot, as an offset into the dynamic LDS array
+};
+
+// items are issued in order, so the source offsets simply walk down the rows (rows live in tiles of TR rows:
+// consecutive rows are 128 bytes apart inside a tile and a tile apart, minus the rows already walked, at its end)
+template <int M, int K>
+__device__ __forceinline__ void v_issue(VLoadCtx& x)
+{
+    constexpr unsigned TR = ADF_TILE_ROWS;
+    if constexpr (K < VRing<M>::ITEMS) {
+        const unsigned slot = x.ring + (unsigned)(K % VRing<M>::SLOTS) * 1024u;
+        if constexpr (K % 3 == 2) {
+            const unsigned row = x.r0 + 2u * (K / 3) + x.q;
+            v_glds16(x.bC + (row < x.h ? x.wo : x.w_safe), slot);
+            x.wo += 128u;
+        } else {
+            constexpr unsigned i = K - K / 3;
+            v_glds16(x.b0 + (x.r0 + i < x.h ? x.lo : x.line_safe), slot);
+            x.lo += (((x.r0 + i + 1u) & (TR - 1u)) == 0u) ? x.tile_b - (TR - 1u) * 128u : 128u;
+        }
+    }
+}
+
+template <int M, int K>
+__device__ __forceinline__ void v_load_items(VLoadCtx& x, const char* lds, v2f (&c)[M], v2f (&f0)[M], v2f (&f1)[M])
+{
+    if constexpr (K < VRing<M>::ITEMS) {
+        constexpr int S = VRing<M>::SLOTS, T = VRing<M>::ITEMS;
+        v_wait_vm<(K + S - 1 < T ? S - 1 : T - 1 - K)>();
+        const char* s = lds + x.rd + (K % S) * 1024;      // (an index into the __shared__ array: ds_read with an immediate offset)
+        if constexpr (K % 3 == 2) {
+            c[2 * (K / 3)] = *reinterpret_cast<const v2f*>(s);
+            c[2 * (K / 3) + 1] = *reinterpret_cast<const v2f*>(s + 64);
+        } else {
+            f0[K - K / 3] = *reinterpret_cast<const v2f*>(s);
+            f1[K - K / 3] = *reinterpret_cast<const v2f*>(s + 64);
+        }
+        if constexpr (K + S < T) {
+            v_wait_lds();                                   // the slot has been read: it may be filled again
+            v_issue<M, K + S>(x);
+        }
+        v_load_items<M, K + 1>(x, lds, c, f0, f1);
+    }
+}
+
+template <int M, int K>
+__device__ __forceinline__ void v_prime(VLoadCtx& x)
+{
+    if constexpr (K < VRing<M>::SLOTS) { v_issue<M, K>(x); v_prime<M, K + 1>(x); }
+}
+
 template <int M, int R, int EPI>
 __global__ void __launch_bounds__(VT) wave_vpass_kernel(WavePassArgs a)
 {
     __shared__ float nb[4][64][VC];   // next-chunk exchange: GS0, GS1, PS, QS
     __shared__ float red[5][VC][64];  // separator rows by (column, chunk)
     __shared__ float xs[2][VC][64];   // separator solutions
+    extern __shared__ __align__(16) char vring[];   // R == 2: 8 waves x VRing<M>::SLOTS KiB (LDS-DMA landing zone)
     const int tid = threadIdx.x;
     const int xp = tid & 7, cidx = tid >> 3;
+#ifdef ADF_V_STAGGER
+    // Experiment (tools/vstagger.sh): every workgroup of a pass runs the same program for the same time, so the CUs
+    // stay in step -- all loading, then all computing.  Delay the first round's workgroups by a fraction of the
+    // period so that later rounds inherit the offset.
+    {
+        const unsigned lin = blockIdx.y * gridDim.x + blockIdx.x;
+        if (lin < 256u) {
+            const unsigned g = (lin / 8u) % ADF_V_STAGGER;           // (blocks b, b+8, .. share an XCD)
+            for (unsigned k = 0; k < g * ADF_V_STAGGER_UNIT; k++) __builtin_amdgcn_s_sleep(127);
+        }
+    }
+#endif
     ADF_STAMP(0); ADF_WSTAMP(0);
 #ifdef ADF_V_PHASE_TIMING
     if (EPI == EPI_PLANES && threadIdx.x == 0)   // hwreg(HW_REG_XCC_ID) and hwreg(HW_REG_HW_ID), 32 bits each
@@ -99,7 +203,34 @@ __global__ void __launch_bounds__(VT) wave_vpass_kernel(WavePassArgs a)
     // row 0 of the column: always inside the planes
     const unsigned safe = (R > 1) ? ((unsigned)strip * (32u * TR) + 2u * xp) * 4u : (unsigned)col * 4u;
     const unsigned csafe = ((unsigned)strip * (unsigned)h * VC + 2u * xp) * 4u;
-    {
+    v2f a_s = vsplat(0.0f);
+    if (cidx > 0 && r0 - 1 < h) a_s = *reinterpret_cast<const v2f*>(bC + (coff0 - pitch_c)) * vsplat(a.lambda);
+    if constexpr (R > 1 && ADF_V_GLDS) {
+        // Rows past the end of the column are fetched from row 0 of the same strip (always inside the planes) and NOT
+        // masked: Cvert is 0 in the last row (FGS.cpp:658-660), so whatever finite, diagonally dominant system those
+        // rows form is decoupled from the real one by exact zeros (0 * finite), and the stores below skip them.
+        VLoadCtx x;
+        x.bC = bC; x.b0 = b0;
+        const unsigned piece = 16u * (unsigned)xp;
+        x.line_safe = (unsigned)strip * (32u * TR) * 4u + piece;
+        // (an opaque copy of the chunk's first row: the row tests of the load phase must not be shared with the store
+        // phase's, or one register per row stays alive across the whole solve)
+        unsigned r0l = (unsigned)r0;
+        asm volatile("" : "+v"(r0l));
+        x.lo = ((r0l / TR) * (2u * TR * (unsigned)a.pitch) + (unsigned)strip * (32u * TR) + (r0l % TR) * 32u) * 4u + piece;
+        x.q = (unsigned)xp >> 2;
+        x.w_safe = ((unsigned)strip * (unsigned)h) * (VC * 4u) + 16u * ((unsigned)xp & 3u);
+        x.wo = ((unsigned)strip * (unsigned)h + r0l + x.q) * (VC * 4u) + 16u * ((unsigned)xp & 3u);
+        x.tile_b = tile_b; x.r0 = r0l; x.h = (unsigned)h;
+        char* ringp = vring + (tid >> 6) * (VRing<M>::SLOTS * 1024);
+        x.ring = __builtin_amdgcn_readfirstlane((unsigned)(size_t)ringp);
+        x.rd = (unsigned)((tid >> 6) * (VRing<M>::SLOTS * 1024) + ((tid >> 3) & 7) * 128 + xp * 8);
+        v_prime<M, 0>(x);
+        v_load_items<M, 0>(x, vring, c, f0, f1);
+        const v2f lam = vsplat(a.lambda);
+#pragma unroll
+        for (int i = 0; i < M; i++) c[i] *= lam;
+    } else {
         // Rows past the end of the column are loaded from row 0 of the same column (always inside the
         // planes, no load under a divergent branch) and NOT masked: Cvert is 0 in the last row
         // (FGS.cpp:658-660), so whatever finite, diagonally dominant system those rows form is decoupled
@@ -120,8 +251,6 @@ __global__ void __launch_bounds__(VT) wave_vpass_kernel(WavePassArgs a)
 #pragma unroll
         for (int i = 0; i < M; i++) c[i] *= lam;
     }
-    v2f a_s = vsplat(0.0f);
-    if (cidx > 0 && r0 - 1 < h) a_s = *reinterpret_cast<const v2f*>(bC + (coff0 - pitch_c)) * vsplat(a.lambda);
 
     ADF_DRAIN(); ADF_STAMP(1);
     Boundary2<R> bd;
@@ -234,11 +363,34 @@ __global__ void __launch_bounds__(VT) wave_vpass_kernel(WavePassArgs a)
     ADF_STAMP(5); ADF_DRAIN(); ADF_STAMP(6); ADF_WSTAMP(1);
 }
 
+// Dynamic LDS of a two-right-hand-side instantiation: the wave rings of the LDS-DMA loads.  Beyond 48 KiB the function
+// needs its limit raised -- per function AND device, so the "already done" note is kept per device.
+template <typename K>
+hipError_t v_allow_lds(K kernel, size_t bytes)
+{
+    static unsigned long long done = 0;                       // bit d: raised on device d (devices >= 64: every launch)
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return hipErrorInvalidDevice;
+    if (dev < 64 && (__atomic_load_n(&done, __ATOMIC_RELAXED) >> dev & 1ull)) return hipSuccess;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    if (e == hipSuccess && dev < 64) __atomic_fetch_or(&done, 1ull << dev, __ATOMIC_RELAXED);
+    return e;
+}
+
 template <int M>
 hipError_t launch_v(const WavePassArgs& a, int n_rhs, int epi, int n_pairs, hipStream_t st)
 {
     dim3 grid(a.pitch / VC, n_pairs), block(VT);
-#define ADF_LV(RR, EE) hipLaunchKernelGGL((wave_vpass_kernel<M, RR, EE>), grid, block, 0, st, a)
+    const size_t ring = (size_t)(VT / 64) * VRing<M>::SLOTS * 1024;
+#define ADF_LV(RR, EE)                                                                                        \
+    do {                                                                                                      \
+        const size_t lds = ((RR) > 1 && ADF_V_GLDS) ? ring : 0;                                               \
+        if (lds > 16 * 1024) {                                                                                \
+            hipError_t e = v_allow_lds(wave_vpass_kernel<M, RR, EE>, lds);                                    \
+            if (e != hipSuccess) return e;                                                                    \
+        }                                                                                                     \
+        hipLaunchKernelGGL((wave_vpass_kernel<M, RR, EE>), grid, block, lds, st, a);                          \
+    } while (0)
     if (n_rhs == 2 && epi == EPI_PLANES) ADF_LV(2, EPI_PLANES);
     else if (n_rhs == 2 && epi == EPI_WLS_CONF) ADF_LV(2, EPI_WLS_CONF);
     else if (n_rhs == 1 && epi == EPI_PLANES) ADF_LV(1, EPI_PLANES);

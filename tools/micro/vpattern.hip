@@ -1,0 +1,255 @@
+// vpattern.hip -- what bounds the column pass's data movement? (round 3)
+//
+// The column pass (csrc/fgs_wave_v.hip) moves exactly its algorithmic bytes, yet runs at 4.6 TB/s where the row pass
+// reaches 5.5: with the solve arithmetic removed it is no faster, so the limit is how the bytes move.  Its loads are
+// "fragment-shaped": a thread owns (chunk, column pair), so one wave instruction fetches 8 rows x 64 bytes, 8 bytes per
+// lane.  This program moves the same bytes of the same layout (strip-major weights, pair plane in 2-row tiles) with
+//   L0  the kernel's own loads (8 B per lane, 8 half lines per instruction)
+//   L1  LDS-DMA loads of whole 128-byte lines (16 B per lane, 8 lines per instruction) into a per-wave LDS ring, then
+//       8-byte LDS reads into the same registers
+//   S0  the kernel's own stores (8 B per lane)
+//   S1  stores of whole lines (16 B per lane) staged through a per-wave LDS slot
+// and prints the rate of every combination plus load-only / store-only legs.
+//   hipcc -O3 --offload-arch=gfx950 tools/micro/vpattern.hip -o tools/micro/vpattern && tools/micro/vpattern [pairs]
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e_)); exit(1); } } while (0)
+
+#ifndef VCW
+#define VCW 16
+#endif
+constexpr int M = 34, VC = VCW, VT = 512, TR = 2, NS = 12;
+constexpr int XP = VC / 2, CH = VT / XP, LPR = VC / 2;   // column pairs, chunks per workgroup, 16-byte pieces per pair-plane row
+constexpr int CPW = 64 / LPR;                            // chunks per wave instruction of the LDS-DMA
+typedef float v2f __attribute__((ext_vector_type(2)));
+typedef float v4f __attribute__((ext_vector_type(4)));
+
+struct Args { float* C; float* U; int pitch, h; size_t plane; };
+
+template <int N> __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" :: "n"(N) : "memory"); }
+__device__ __forceinline__ void wait_lds() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+
+// one LDS-DMA instruction: every lane 16 bytes from its own address, image lane-linear at lds_dst (wave-uniform)
+__device__ __forceinline__ void glds16(const void* gsrc, unsigned lds_dst)
+{
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+}
+
+enum { F_GLDS = 1, F_LSTORE = 2, F_NOLOAD = 4, F_NOSTORE = 8, F_WINDOW = 16 };   // F_WINDOW: L0 in groups of 8 rows, a wait per group
+
+struct Ctx {
+    const char* bC; char* b0; unsigned tile_b, strip, h, rbase; int wv, lane, j, p, xp, cidx, r0;
+};
+
+// byte offset of pair-plane row `row` of the strip (start of its 128-byte line [U0 x16 | U1 x16])
+__device__ __forceinline__ unsigned line_off(const Ctx& c, unsigned row, unsigned pitch)
+{
+    return ((row / TR) * (2u * TR * pitch) + c.strip * (2u * VC * TR) + (row % TR) * 2u * VC) * 4u;
+}
+
+template <int K, int MODE>
+struct Items {
+    // item K of the 51-item load sequence L0 L1 W0 L2 L3 W1 ...: K % 3 == 2 -> weight rows 2*(K/3), 2*(K/3)+1
+    static __device__ __forceinline__ void issue(const Ctx& c, unsigned pitch, unsigned ring)
+    {
+        if constexpr (K < 51) {
+            const unsigned slot = ring + (unsigned)(K % NS) * 1024u;
+            if constexpr (K % 3 == 2) {
+                const unsigned i2 = K / 3;
+                constexpr int WP = VC / 4;                              // 16-byte pieces per weight row
+                unsigned row = (unsigned)c.r0 + 2u * i2 + (unsigned)(c.p / WP);
+                row = row < c.h ? row : c.rbase;
+                glds16(c.bC + ((c.strip * c.h + row) * VC) * 4u + (unsigned)(c.p % WP) * 16u, slot);
+            } else {
+                const unsigned i = K - K / 3;
+                unsigned row = (unsigned)c.r0 + i;
+                row = row < c.h ? row : c.rbase;
+                glds16(c.b0 + line_off(c, row, pitch) + (unsigned)c.p * 16u, slot);
+            }
+        }
+    }
+    static __device__ __forceinline__ void consume(const Ctx& c, const char* ringp, v2f (&cc)[M], v2f (&f0)[M], v2f (&f1)[M])
+    {
+        const char* s = ringp + (K % NS) * 1024 + c.j * (8 * VC) + c.xp * 8;
+        if constexpr (K % 3 == 2) {
+            cc[2 * (K / 3)] = *reinterpret_cast<const v2f*>(s);
+            cc[2 * (K / 3) + 1] = *reinterpret_cast<const v2f*>(s + 4 * VC);
+        } else {
+            f0[K - K / 3] = *reinterpret_cast<const v2f*>(s);
+            f1[K - K / 3] = *reinterpret_cast<const v2f*>(s + 4 * VC);
+        }
+    }
+};
+
+template <int K, int MODE>
+__device__ __forceinline__ void glds_loop(const Ctx& c, unsigned pitch, unsigned ring, const char* ringp, v2f (&cc)[M], v2f (&f0)[M], v2f (&f1)[M])
+{
+    if constexpr (K < 51) {
+        // items K .. min(K+NS-1, 50) are in flight: item K is done when at most that many minus one are outstanding
+        constexpr int younger = (K + NS - 1 < 51 ? NS - 1 : 50 - K);
+        wait_vm<younger>();
+        Items<K, MODE>::consume(c, ringp, cc, f0, f1);
+        wait_lds();                                          // the slot is free again
+        Items<K + NS, MODE>::issue(c, pitch, ring);
+        glds_loop<K + 1, MODE>(c, pitch, ring, ringp, cc, f0, f1);
+    }
+}
+
+template <int K, int MODE>
+__device__ __forceinline__ void glds_prime(const Ctx& c, unsigned pitch, unsigned ring)
+{
+    if constexpr (K < NS) { Items<K, MODE>::issue(c, pitch, ring); glds_prime<K + 1, MODE>(c, pitch, ring); }
+}
+
+template <int MODE>
+__global__ void __launch_bounds__(VT) vpat(Args a)
+{
+    extern __shared__ __align__(16) char lds[];
+    const int tid = threadIdx.x;
+    Ctx c;
+    c.wv = tid >> 6; c.lane = tid & 63; c.j = c.lane / LPR; c.p = c.lane % LPR; c.xp = tid % XP; c.cidx = tid / XP;
+    c.rbase = blockIdx.z * (CH * M); c.r0 = (int)c.rbase + c.cidx * M;     // blockIdx.z: which part of the column
+    c.strip = blockIdx.x; c.h = (unsigned)a.h;
+    const size_t pb = (size_t)blockIdx.y * a.plane;
+    c.bC = reinterpret_cast<const char*>(a.C + pb);
+    c.b0 = reinterpret_cast<char*>(a.U + 2 * pb);
+    const unsigned pitch = (unsigned)a.pitch;
+    char* ringp = lds + c.wv * (NS * 1024);
+    const unsigned ring = __builtin_amdgcn_readfirstlane((unsigned)(size_t)ringp);   // LDS byte address (wave-uniform -> SGPR)
+    v2f cc[M], f0[M], f1[M];
+#pragma unroll
+    for (int i = 0; i < M; i++) { cc[i] = (v2f){1.f, 1.f}; f0[i] = (v2f){(float)i, 2.f}; f1[i] = (v2f){3.f, (float)tid}; }
+    if (!(MODE & F_NOLOAD)) {
+        if (MODE & F_GLDS) {
+            glds_prime<0, MODE>(c, pitch, ring);
+            glds_loop<0, MODE>(c, pitch, ring, ringp, cc, f0, f1);
+        } else {
+#pragma unroll
+            for (int i = 0; i < M; i++) {
+                unsigned row = (unsigned)c.r0 + i; row = row < c.h ? row : c.rbase;
+                cc[i] = *reinterpret_cast<const v2f*>(c.bC + ((c.strip * c.h + row) * VC + 2u * c.xp) * 4u);
+                f0[i] = *reinterpret_cast<const v2f*>(c.b0 + line_off(c, row, pitch) + c.xp * 8u);
+                f1[i] = *reinterpret_cast<const v2f*>(c.b0 + line_off(c, row, pitch) + 4u * VC + c.xp * 8u);
+                __builtin_amdgcn_sched_barrier(0);
+                if ((MODE & F_WINDOW) && (i & 7) == 7) {
+#pragma unroll
+                    for (int k = i - 7; k <= i; k++) asm volatile("" : "+v"(cc[k]), "+v"(f0[k]), "+v"(f1[k]));
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < M; i++) { f0[i] = f0[i] * cc[i] + f1[i]; f1[i] = f1[i] - cc[i]; asm volatile("" : "+v"(f0[i]), "+v"(f1[i])); }
+    if (!(MODE & F_NOSTORE)) {
+        if (MODE & F_LSTORE) {
+            // per wave: rows i of its 8 chunks = 8 whole lines = one 1 KiB image, two slots alternating
+#pragma unroll
+            for (int i = 0; i < M; i++) {
+                char* s = ringp + (i & 3) * 1024;
+                *reinterpret_cast<v2f*>(s + c.j * (8 * VC) + c.xp * 8) = f0[i];
+                *reinterpret_cast<v2f*>(s + c.j * (8 * VC) + 4 * VC + c.xp * 8) = f1[i];
+                wait_lds();
+                const v4f q = *reinterpret_cast<const v4f*>(s + c.lane * 16);
+                const unsigned row = (unsigned)c.r0 + i;
+                if (row < c.h) *reinterpret_cast<v4f*>(c.b0 + line_off(c, row, pitch) + (unsigned)c.p * 16u) = q;
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < M; i++) {
+                const unsigned row = (unsigned)c.r0 + i;
+                if (row < c.h) {
+                    *reinterpret_cast<v2f*>(c.b0 + line_off(c, row, pitch) + c.xp * 8u) = f0[i];
+                    *reinterpret_cast<v2f*>(c.b0 + line_off(c, row, pitch) + 4u * VC + c.xp * 8u) = f1[i];
+                }
+            }
+        }
+    } else {
+        float acc = 0.f;
+#pragma unroll
+        for (int i = 0; i < M; i++) acc += f0[i].x + f0[i].y + f1[i].x + f1[i].y;
+        if (acc == 123456.789f) a.U[0] = acc;                // keeps the loads alive
+    }
+}
+
+template <int MODE>
+float run(const Args& a, int pairs, int reps, size_t lds)
+{
+    CK(hipFuncSetAttribute(reinterpret_cast<const void*>(vpat<MODE>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    dim3 grid(a.pitch / VC, pairs, (a.h + CH * M - 1) / (CH * M)), block(VT);
+    hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    for (int w = 0; w < 2; w++) hipLaunchKernelGGL(vpat<MODE>, grid, block, lds, 0, a);
+    CK(hipEventRecord(e0));
+    for (int r = 0; r < reps; r++) hipLaunchKernelGGL(vpat<MODE>, grid, block, lds, 0, a);
+    CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1)); CK(hipGetLastError());
+    float ms = 0; CK(hipEventElapsedTime(&ms, e0, e1));
+    return ms / reps;
+}
+
+__global__ void fill_kernel(float* p, size_t n, unsigned seed)
+{
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] = (float)((((unsigned)i + seed) * 2654435761u) >> 12) * (1.0f / 1048576.0f);
+}
+
+// L1+S1 and every mix must produce exactly what L0+S0 produces on the same data
+static bool verify()
+{
+    Args a; a.pitch = 3584; a.h = 2160; a.plane = (size_t)a.pitch * a.h;
+    float* U[4];
+    CK(hipMalloc(&a.C, a.plane * 4));
+    hipLaunchKernelGGL(fill_kernel, dim3((unsigned)((a.plane + 255) / 256)), dim3(256), 0, 0, a.C, a.plane, 7u);
+    const size_t lds = 8 * NS * 1024 + 44 * 1024;
+    std::vector<float> ref(a.plane * 2), got(a.plane * 2);
+    bool ok = true;
+    for (int m = 0; m < 4; m++) {
+        CK(hipMalloc(&U[m], a.plane * 8));
+        hipLaunchKernelGGL(fill_kernel, dim3((unsigned)((a.plane * 2 + 255) / 256)), dim3(256), 0, 0, U[m], a.plane * 2, 99u);
+        a.U = U[m];
+        dim3 grid(a.pitch / VC, 1, (a.h + CH * M - 1) / (CH * M)), block(VT);
+        if (m == 0) hipLaunchKernelGGL(vpat<0>, grid, block, lds, 0, a);
+        if (m == 1) { CK(hipFuncSetAttribute(reinterpret_cast<const void*>(vpat<F_GLDS>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); hipLaunchKernelGGL(vpat<F_GLDS>, grid, block, lds, 0, a); }
+        if (m == 2) { CK(hipFuncSetAttribute(reinterpret_cast<const void*>(vpat<F_LSTORE>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); hipLaunchKernelGGL(vpat<F_LSTORE>, grid, block, lds, 0, a); }
+        if (m == 3) { CK(hipFuncSetAttribute(reinterpret_cast<const void*>(vpat<F_GLDS | F_LSTORE>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); hipLaunchKernelGGL(vpat<F_GLDS | F_LSTORE>, grid, block, lds, 0, a); }
+        CK(hipDeviceSynchronize());
+        CK(hipMemcpy(m == 0 ? ref.data() : got.data(), U[m], a.plane * 8, hipMemcpyDeviceToHost));
+        if (m > 0) {
+            size_t bad = 0;
+            for (size_t i = 0; i < ref.size(); i++) bad += ref[i] != got[i];
+            printf("  verify mode %d vs the kernel's own pattern: %zu differing floats\n", m, bad);
+            ok = ok && bad == 0;
+        }
+        CK(hipFree(U[m]));
+    }
+    CK(hipFree(a.C));
+    return ok;
+}
+
+int main(int argc, char** argv)
+{
+    if (!verify()) { printf("VERIFY FAILED\n"); return 1; }
+    const int pairs = argc > 1 ? atoi(argv[1]) : 16;
+    Args a; a.pitch = 3584; a.h = 2160; a.plane = (size_t)a.pitch * a.h;
+    CK(hipMalloc(&a.C, a.plane * 4 * pairs)); CK(hipMalloc(&a.U, a.plane * 8 * pairs));
+    CK(hipMemset(a.C, 0, a.plane * 4 * pairs)); CK(hipMemset(a.U, 0, a.plane * 8 * pairs));
+    const double px = (double)a.plane * pairs;
+    const size_t lds = 8 * NS * 1024 + 44 * 1024;            // the real kernel's exchange buffers ride along
+    struct { const char* name; float ms; double bytes; } r[] = {
+        {"L0+S0 (as the kernel)", run<0>(a, pairs, 10, lds), 20 * px},
+        {"L1+S0 (LDS-DMA whole lines)", run<F_GLDS>(a, pairs, 10, lds), 20 * px},
+        {"L0+S1 (whole-line stores)", run<F_LSTORE>(a, pairs, 10, lds), 20 * px},
+        {"L1+S1", run<F_GLDS | F_LSTORE>(a, pairs, 10, lds), 20 * px},
+        {"L0w+S0 (8-row windows)", run<F_WINDOW>(a, pairs, 10, lds), 20 * px},
+        {"L0 only", run<F_NOSTORE>(a, pairs, 10, lds), 12 * px},
+        {"L1 only", run<F_GLDS | F_NOSTORE>(a, pairs, 10, lds), 12 * px},
+        {"S0 only", run<F_NOLOAD>(a, pairs, 10, lds), 8 * px},
+        {"S1 only", run<F_NOLOAD | F_LSTORE>(a, pairs, 10, lds), 8 * px},
+    };
+    printf("column-pass data movement, %d pairs of 3584 x 2160, strips of %d columns, %d chunks of %d rows per workgroup, %d workgroup(s) per strip\n", pairs, VC, CH, M, (a.h + CH * M - 1) / (CH * M));
+    for (auto& x : r) printf("  %-32s %8.3f ms  %7.1f GB/s  (x64/pairs: %.3f ms)\n", x.name, x.ms, x.bytes / x.ms / 1e6, x.ms * 64.0 / pairs);
+    return 0;
+}
