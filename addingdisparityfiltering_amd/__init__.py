@@ -11,6 +11,7 @@ from .ximgproc import (  # noqa: F401
     FastGlobalSmootherFilter,
     PATH_CONF_BAND,
     PATH_FUSED_FIRST_PASS,
+    PATH_MERGED_PREP,
     SOLVER_EXACT,
     SOLVER_WAVE,
     StereoBM,

@@ -306,6 +306,7 @@ struct adf_wls {
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     bool overlap = true;
     bool conf_band = true;   // ADF_CONF_BAND=0: the two-kernel confidence stage (A/B measurements)
+    bool merge_small = true; // ADF_MERGE_SMALL=0: never the merged preparation launch (A/B measurements)
     int ensure_side()
     {
         if (side) return ADF_OK;
@@ -336,6 +337,7 @@ extern "C" int adf_wls_create(adf_wls_t** out, int use_confidence, int l, int r,
     }
     if (const char* e = getenv("ADF_NO_OVERLAP")) h->overlap = atoi(e) == 0;   // measurement knob
     if (const char* e = getenv("ADF_CONF_BAND")) h->conf_band = atoi(e) != 0;    // measurement knob
+    if (const char* e = getenv("ADF_MERGE_SMALL")) h->merge_small = atoi(e) != 0;   // measurement knob
     *out = h;
     return ADF_OK;
 }
@@ -529,7 +531,9 @@ static int wls_filter_impl(adf_wls_t* h, int n_pairs,
         // confidence mode: the weights depend on the guide only and the confidence kernels on the disparity
         // maps only -- one is bound by memory latency, the others lean on the vector ALUs -- so the weight
         // kernel is forked onto the side stream and joined before the first solve pass
-        const bool fork_weights = conf && h->overlap;
+        // one small frame per call: weights, confidence map and fill in ONE launch on the caller's stream (no fork)
+        const bool merged = band && h->merge_small && prep_small_fits(g, h->disc_radius, gch, n);
+        const bool fork_weights = conf && h->overlap && !merged;
         hipStream_t wst = st;
         if (fork_weights) {
             if ((rc = h->ensure_side())) return rc;
@@ -537,9 +541,18 @@ static int wls_filter_impl(adf_wls_t* h, int n_pairs,
             HIP_TRY(hipStreamWaitEvent(h->side, h->ev_fork, 0));
             wst = h->side;
         }
-        {
+        if (!merged) {
             ProfScope ps(prof, K_WEIGHTS, (gch + 8.0) * P, (gch + 8.0) * P, wst);
             HIP_TRY(launch_weights(wa, n, wst));                           // FGS.cpp:163-172
+        }
+        // the fill of everything outside the ROI (DF.cpp:284, :187-190) touches no pixel any other kernel of the call
+        // touches: on the wave path it rides the side stream too instead of sitting between the confidence kernel and
+        // the first solve pass (one dependent launch less on the critical path of a single-pair call)
+        const bool outside_on_side = fork_weights && !conf_given && wave && h->disc_radius <= conf_left_max_radius();
+        if (outside_on_side) {
+            OutsideArgs oa{o, sO, psO, fill, (float*)h->conf.p + (size_t)first * g.cframe, g};
+            ProfScope ps(prof, K_FILL, 6.0 * (F - P), 6.0 * (F - P), wst);
+            HIP_TRY(launch_outside(oa, n, wst));
         }
         if (fork_weights) HIP_TRY(hipEventRecord(h->ev_join, h->side));
 
@@ -581,7 +594,14 @@ static int wls_filter_impl(adf_wls_t* h, int n_pairs,
                 if (!fused_h) fuse = WavePassArgs{};
                 if (band && !fused_h) return fail(ADF_EHIP, "internal: confidence kernel selection and first-pass fusion disagree");
                 if (band) h->last_path |= ADF_PATH_CONF_BAND;
-                if (band) {
+                if (merged) {
+                    h->last_path |= ADF_PATH_MERGED_PREP;
+                    ConfBandArgs ba{dL, sL, psL, dRp, sR, psR, confp, g, rrx, thresh, h->disc_radius, h->roll_off, 0};
+                    OutsideArgs oa{o, sO, psO, fill, confp, g};
+                    const double b = (8.0 + gch + 8.0) * P + 6.0 * (F - P);
+                    ProfScope ps(prof, K_LRC, b, b, st);
+                    HIP_TRY(launch_prep_small(ba, wa, oa, n, st));         // FGS.cpp:163-172 + DF.cpp:197-210 + :284
+                } else if (band) {
                     // both views, LRC and x255 in one band sweep: the right view's map lives in LDS only
                     ConfBandArgs ba{dL, sL, psL, dRp, sR, psR, confp, g, rrx, thresh, h->disc_radius, h->roll_off, 0};
                     ProfScope ps(prof, K_LRC, 8.0 * P, 8.0 * P, st);     // dL 2 + dR 2 read, conf 4 written
@@ -598,8 +618,8 @@ static int wls_filter_impl(adf_wls_t* h, int n_pairs,
                     ProfScope ps(prof, K_LRC, (4.0 + wu) * P, (12.0 + wu) * P, st);
                     HIP_TRY(launch_conf_left(ca, n, st));                  // DF.cpp:204-209 (+288-290)
                 }
-                OutsideArgs oa{o, sO, psO, fill, confp, g};
-                {
+                if (!outside_on_side && !merged) {
+                    OutsideArgs oa{o, sO, psO, fill, confp, g};
                     ProfScope ps(prof, K_FILL, 6.0 * (F - P), 6.0 * (F - P), st);
                     HIP_TRY(launch_outside(oa, n, st));                    // DF.cpp:284, :187-190
                 }

@@ -14,6 +14,7 @@
 // All of this is integer / elementwise float work: HBM-bound, no MFMA.  Arithmetic that must
 // match the CPU restatement bit for bit is written as separate roundings (contraction off).
 #include "adf_internal.h"
+#include "prep_bodies.h"
 
 #pragma clang fp contract(off)
 
@@ -438,21 +439,21 @@ __device__ __forceinline__ void band_row_values(const ColSum (&V)[CB_COLS], doub
     }
 }
 
+// (band `band` of image `pz`; smem = the workgroup's dynamic LDS.  Waves past the ROI's width own no columns and only
+// keep the barriers company: the merged preparation kernel launches at least four waves per block.)
 template <int RT>
-__global__ void __launch_bounds__(64 * CB_MAX_WAVES) conf_band_kernel(ConfBandArgs a)
+__device__ __forceinline__ void conf_band_body(const ConfBandArgs& a, const int band, const size_t pz, unsigned char* smem)
 {
     constexpr int K = 2 * RT + 1;
     constexpr int RING = RT + 2;                       // raw right rows kept in LDS (centre row + one row of slack for the slowest wave)
     typedef int v2i_u __attribute__((ext_vector_type(2), aligned(2)));
     typedef float v4f_u __attribute__((ext_vector_type(4), aligned(4)));
-    extern __shared__ __align__(16) unsigned char smem[];
     const Geom& g = a.g;
     const int rw = g.rw, rwp = (rw + 3) & ~3;
     float* crow = reinterpret_cast<float*>(smem);                     // [2][rwp]   right map of the current row
     int16_t* draw = reinterpret_cast<int16_t*>(crow + 2 * rwp);       // [RING][rwp] raw right disparities
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const size_t pz = blockIdx.y;
-    const int y0 = blockIdx.x * a.rows_per_band;
+    const int y0 = band * a.rows_per_band;
     const int rows_out = min(a.rows_per_band, g.rh - y0);
     const int nrows = rows_out + 2 * RT;               // input rows this band consumes
     constexpr int HL = CB_HALO(RT);
@@ -575,19 +576,26 @@ __global__ void __launch_bounds__(64 * CB_MAX_WAVES) conf_band_kernel(ConfBandAr
 #undef CB_ELEM
 }
 
+template <int RT>
+__global__ void __launch_bounds__(64 * CB_MAX_WAVES) conf_band_kernel(ConfBandArgs a)
+{
+    extern __shared__ __align__(16) unsigned char smem[];
+    conf_band_body<RT>(a, blockIdx.x, blockIdx.y, smem);
+}
+
 constexpr int OUT_ROWS = 16; // rows per block of outside_kernel
 
 // Non-ROI pixels of the frame: the side columns of the ROI's rows (part A: W - rw columns x rh rows, blocks of NT
 // columns x OUT_ROWS rows) and the whole rows above / below the ROI (part B: (H - rh) x W pixels, a flat index in
 // blocks of NT * OUT_ROWS pixels).  blockIdx.x < nA: part A, else part B -- no block without work (round 3: the BM
 // factory's ROI has rows outside it, and a grid over the whole frame spent 0.49 ms per 64 x 4K step finding that out).
-__global__ void __launch_bounds__(NT) outside_kernel(OutsideArgs a, int nAx, int nA)
+__device__ __forceinline__ void outside_body(const OutsideArgs& a, const int nAx, const int nA, const unsigned blk, const size_t pz)
 {
     const Geom& g = a.g;
-    char* out = a.out ? reinterpret_cast<char*>(a.out) + (ptrdiff_t)blockIdx.z * a.pair_stride : nullptr;
-    float* conf = a.conf ? a.conf + (size_t)blockIdx.z * g.cframe + g.cx0 : nullptr;
-    if ((int)blockIdx.x < nA) {
-        const int bx = blockIdx.x % nAx, by = blockIdx.x / nAx;
+    char* out = a.out ? reinterpret_cast<char*>(a.out) + (ptrdiff_t)pz * a.pair_stride : nullptr;
+    float* conf = a.conf ? a.conf + pz * g.cframe + g.cx0 : nullptr;
+    if ((int)blk < nA) {
+        const int bx = blk % nAx, by = blk / nAx;
         const int t = bx * NT + threadIdx.x;
         if (t >= g.W - g.rw) return;
         const int j = t < g.rx ? t : t + g.rw;
@@ -598,7 +606,7 @@ __global__ void __launch_bounds__(NT) outside_kernel(OutsideArgs a, int nAx, int
         }
     } else {
         const size_t npix = (size_t)(g.H - g.rh) * g.W;
-        size_t p = (size_t)(blockIdx.x - nA) * (NT * OUT_ROWS) + threadIdx.x;
+        size_t p = (size_t)(blk - nA) * (NT * OUT_ROWS) + threadIdx.x;
 #pragma unroll 4
         for (int k = 0; k < OUT_ROWS; k++, p += NT) {
             if (p >= npix) break;
@@ -608,6 +616,42 @@ __global__ void __launch_bounds__(NT) outside_kernel(OutsideArgs a, int nAx, int
             if (out) reinterpret_cast<int16_t*>(out + (ptrdiff_t)i * a.stride)[j] = a.fill;
             if (conf) conf[(size_t)i * g.cpitch + j] = 0.0f;
         }
+    }
+}
+
+__global__ void __launch_bounds__(NT) outside_kernel(OutsideArgs a, int nAx, int nA)
+{
+    outside_body(a, nAx, nA, blockIdx.x, blockIdx.z);
+}
+
+// ---------------------------------------------------------------------------------------
+// Everything a confidence-mode call prepares before its first solve pass, in ONE launch (round 3): blocks
+// [0, nC) are bands of the one-sweep confidence kernel (the longest role first), [nC, nC + nW) blocks of the streaming
+// weight kernel, the rest fill what lies outside the ROI.  The three touch disjoint data, so for batches they are
+// separate launches on two streams (adf_api.hip); for ONE small frame per call the cross-stream event and launch
+// latencies are a third of the call (profiles/r03_latency_timeline.txt), which this kernel removes.  Blocks are as
+// wide as the confidence role needs (at least the weight role's 256 threads); waves a role has no use for only keep
+// its barriers company.
+// ---------------------------------------------------------------------------------------
+struct PrepArgs {
+    ConfBandArgs c; WeightArgs w; OutsideArgs o;
+    int nC, nW, nWx, nWy, nOAx, nOA;
+};
+
+template <int CH, int RT>
+__global__ void __launch_bounds__(64 * CB_MAX_WAVES) prep_small_kernel(PrepArgs a)
+{
+    extern __shared__ __align__(16) unsigned char smem[];
+    __shared__ prep::WsShared<CH> ws;
+    const unsigned b = blockIdx.x;
+    const size_t pz = blockIdx.y;
+    if ((int)b < a.nC) {
+        conf_band_body<RT>(a.c, (int)b, pz, smem);
+    } else if ((int)b < a.nC + a.nW) {
+        const int k = (int)b - a.nC;
+        prep::weights_stream_body<CH>(a.w, k % a.nWx, k / a.nWx, a.nWy, pz, ws, threadIdx.x < prep::WS_NT);
+    } else {
+        if (threadIdx.x < NT) outside_body(a.o, a.nOAx, a.nOA, b - (unsigned)(a.nC + a.nW), pz);
     }
 }
 
@@ -837,10 +881,13 @@ hipError_t launch_conf_band(const ConfBandArgs& a0, int n_pairs, hipStream_t st)
     ConfBandArgs a = a0;
     const int waves = (a.g.rw + CB_WOUT(a.radius) - 1) / CB_WOUT(a.radius);
     // bands: tall (the 2*RT halo rows and the K-row ramp are paid per band), but enough workgroups for two rounds
-    // of the chip's 256 CUs when the batch allows it
+    // of the chip's 256 CUs when the batch allows it.  A band is walked row by row (one workgroup barrier per row,
+    // ~1.3 us each): with few pairs per call the band height IS the kernel's latency (one 1242x375 frame in 32-row
+    // bands: 12 workgroups, 47 us), so small calls get bands down to max(4, 2 * radius) rows (round 3).
     int bands = (512 + n_pairs - 1) / n_pairs;
     int rpb = (a.g.rh + bands - 1) / bands;
-    if (rpb < 32) rpb = 32;
+    const int min_rpb = 2 * a.radius > 4 ? 2 * a.radius : 4;     // (at least as many output rows as halo rows)
+    if (rpb < min_rpb) rpb = min_rpb;
     if (rpb > a.g.rh) rpb = a.g.rh;
     a.rows_per_band = rpb;
     const dim3 grid((a.g.rh + rpb - 1) / rpb, n_pairs), block(64 * waves);
@@ -857,6 +904,60 @@ hipError_t launch_conf_band(const ConfBandArgs& a0, int n_pairs, hipStream_t st)
         break;
     switch (a.radius) { ADF_CB(1) ADF_CB(2) ADF_CB(3) ADF_CB(4) ADF_CB(5) ADF_CB(6) ADF_CB(7) ADF_CB(8) }
 #undef ADF_CB
+    return hipGetLastError();
+}
+
+// The merged preparation launch: for calls small enough that three kernels' latencies, not their work, are the time.
+bool prep_small_fits(const Geom& g, int radius, int channels, int n_pairs)
+{
+    return conf_band_fits(g, radius) && radius <= 5 && (channels == 1 || channels == 3) &&
+           (double)g.rw * g.rh * n_pairs <= 2.5e6;
+}
+
+hipError_t launch_prep_small(const ConfBandArgs& c0, const WeightArgs& w, const OutsideArgs& o, int n_pairs, hipStream_t st)
+{
+    if (!prep_small_fits(c0.g, c0.radius, w.ch, n_pairs)) return hipErrorInvalidValue;
+    if (!(w.chor_orient == ORIENT_N && w.cvert_orient == ORIENT_STRIP)) return hipErrorInvalidValue;
+    PrepArgs a{};
+    a.c = c0; a.w = w; a.o = o;
+    const Geom& g = c0.g;
+    int waves = (g.rw + CB_WOUT(c0.radius) - 1) / CB_WOUT(c0.radius);
+    if (waves < prep::WS_NT / 64) waves = prep::WS_NT / 64;
+    // short bands and few rows per weight block: every role is walked row by row, a barrier per row
+    // (as short as the halo allows while that still leaves no more than about one band per CU, and about two weight
+    // blocks per CU: beyond that the roles only queue behind each other)
+    int rpb = 2 * c0.radius > 4 ? 2 * c0.radius : 4;
+    const int rows_all = g.rh * n_pairs;
+    if (rpb < (rows_all + 255) / 256) rpb = (rows_all + 255) / 256;
+    if (rpb > g.rh) rpb = g.rh;
+    a.c.rows_per_band = rpb;
+    a.nC = (g.rh + rpb - 1) / rpb;
+    a.nWx = (g.rw + prep::WS_NT - 1) / prep::WS_NT;
+    int wrows = (rows_all * a.nWx + 511) / 512;
+    if (wrows < 4) wrows = 4;
+    a.nWy = (g.rh + wrows - 1) / wrows;
+    a.nW = a.nWx * a.nWy;
+    const int side = g.W - g.rw;
+    a.nOAx = (side + NT - 1) / NT;
+    a.nOA = side > 0 ? a.nOAx * ((g.rh + OUT_ROWS - 1) / OUT_ROWS) : 0;
+    if (a.nOAx < 1) a.nOAx = 1;
+    const size_t npix = (size_t)(g.H - g.rh) * g.W;
+    const int nOB = (int)((npix + (size_t)NT * OUT_ROWS - 1) / ((size_t)NT * OUT_ROWS));
+    const dim3 grid(a.nC + a.nW + a.nOA + nOB, n_pairs), block(64 * waves);
+    const size_t lds = conf_band_lds(g.rw, c0.radius);
+    if (lds + sizeof(prep::WsShared<3>) > 150 * 1024) return hipErrorInvalidValue;
+#define ADF_PS(CC, RR)                                                                                     \
+    case RR:                                                                                               \
+        if (lds > 32 * 1024) {                                                                             \
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(prep_small_kernel<CC, RR>),   \
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);      \
+            if (e != hipSuccess) return e;                                                                 \
+        }                                                                                                  \
+        hipLaunchKernelGGL((prep_small_kernel<CC, RR>), grid, block, lds, st, a);                          \
+        break;
+    if (w.ch == 1) { switch (c0.radius) { ADF_PS(1, 1) ADF_PS(1, 2) ADF_PS(1, 3) ADF_PS(1, 4) ADF_PS(1, 5) } }
+    else { switch (c0.radius) { ADF_PS(3, 1) ADF_PS(3, 2) ADF_PS(3, 3) ADF_PS(3, 4) ADF_PS(3, 5) } }
+#undef ADF_PS
     return hipGetLastError();
 }
 

@@ -10,6 +10,7 @@
 // row-major [rh][pw]; Chor row-major for the wave solver or transposed [rw][ph] (through an LDS tile)
 // for the exact solver, whose horizontal sweep wants the row index fastest.
 #include "adf_internal.h"
+#include "prep_bodies.h"
 
 namespace adf {
 
@@ -117,113 +118,13 @@ __global__ void __launch_bounds__(NT) weights_kernel(WeightArgs a)
     }
 }
 
-// ---------------------------------------------------------------------------------------
-// Row-major outputs (wave solver): a block walks down a strip of 256 columns.  Each row's guide bytes
-// are fetched once as aligned dwords (prefetched a group of rows ahead), exchanged through a
-// double-buffered LDS row; a thread keeps its own pixel of the previous row in registers, so a row
-// costs CH + CH LDS byte reads, two table look-ups (head of the LUT cached in LDS once per block) and
-// two coalesced 1 KiB stores: Chor of this row and Cvert of the previous one.
-// ---------------------------------------------------------------------------------------
-// rows per block: gridDim.y row blocks share the ROI's rows (see conf_kernels.hip, row_blocks)
-#define WS_ROWS ((g.rh + (int)gridDim.y - 1) / (int)gridDim.y)
-#ifndef ADF_WS_GROUP
-#define ADF_WS_GROUP 16
-#endif
-constexpr int WS_U = ADF_WS_GROUP;
-
+// Row-major outputs (wave solver): the column-walking streaming kernel; its body is shared with the merged preparation
+// kernel of conf_kernels.hip (prep_bodies.h).
 template <int CH>
 __global__ void __launch_bounds__(NT) weights_stream_kernel(WeightArgs a)
 {
-    constexpr int ROWW = ((NT + 1) * CH + 3) / 4 + 1;          // dwords per staged row (incl. misalignment)
-    __shared__ unsigned rowbuf[2][ROWW + 3];
-    __shared__ float lut_head[LUT_HEAD];
-    const Geom& g = a.g;
-    const int tid = threadIdx.x;
-    const int x0 = blockIdx.x * NT, y0 = blockIdx.y * WS_ROWS;
-    const size_t pz = blockIdx.z;
-    const unsigned char* gp = a.guide + (ptrdiff_t)pz * a.pair_stride + (ptrdiff_t)(g.rx + x0) * CH;
-    const int j = x0 + tid;
-    const bool okx = j < g.rw;
-    const int last_px = min(x0 + NT, g.rw - 1);                // right neighbour of the last ROI column is unused
-    const int need = (last_px - x0 + 1) * CH;                  // bytes needed per row
-    const int nrows = min(WS_ROWS, g.rh - y0) + 1;             // one extra row feeds the last vertical difference
-    float* chor = a.chor + pz * g.plane;
-    float* cvert = a.cvert + pz * g.plane;
-    const bool strip = a.cvert_orient == ORIENT_STRIP;
-
-    for (int q = tid; q < LUT_HEAD; q += NT) lut_head[q] = a.lut[q];
-
-    // row n of the block = ROI row min(y0+n, rh-1); returns this thread's aligned dword (or 0)
-    auto row_ptr = [&](int n) { return gp + (ptrdiff_t)(g.ry + min(y0 + n, g.rh - 1)) * a.stride; };
-    auto load = [&](int n) -> unsigned {
-        const unsigned char* rp = row_ptr(n);
-        const int m = (int)(reinterpret_cast<uintptr_t>(rp) & 3u);
-        const int nw = (m + need + 3) >> 2;
-        return tid < nw ? reinterpret_cast<const unsigned*>(rp - m)[tid] : 0u;
-    };
-    // Head of the table from LDS.  The rare large index (a strong colour edge) is fetched with a SCALAR
-    // load, one needy lane at a time: a vector load here -- even one that almost never executes -- makes the
-    // compiler wait for vmcnt(0) before every store of the row loop, and on this target stores count in
-    // vmcnt too, so every row's stores would wait for the previous row's to be acknowledged.
-    auto lookup = [&](int idx) -> float {
-        float w = lut_head[min(idx, LUT_HEAD - 1)];
-        bool need = idx >= LUT_HEAD;
-        unsigned long long m = __ballot(need);
-        while (m) {                                            // wave-uniform
-            const int first = __ffsll((long long)m) - 1;
-            const int sidx = __builtin_amdgcn_readfirstlane(__shfl(idx, first));
-            // constant address space + uniform index = s_load_dword (lgkmcnt, not vmcnt); the table is
-            // written once by the host, long before this launch
-            const float ws = reinterpret_cast<const __attribute__((address_space(4))) float*>(reinterpret_cast<uintptr_t>(a.lut))[sidx];
-            if ((int)(threadIdx.x & 63) == first) { w = ws; need = false; }
-            m = __ballot(need);
-        }
-        return w;
-    };
-
-    int prev[CH];
-#pragma unroll
-    for (int c = 0; c < CH; c++) prev[c] = 0;
-    unsigned nxt[WS_U], cur[WS_U];
-#pragma unroll
-    for (int s = 0; s < WS_U; s++) nxt[s] = (s < nrows) ? load(s) : 0u;
-    for (int n0 = 0; n0 < nrows; n0 += WS_U) {
-#pragma unroll
-        for (int s = 0; s < WS_U; s++) { cur[s] = nxt[s]; asm volatile("" : "+v"(cur[s])); }   // the group's one wait happens here
-#pragma unroll
-        for (int s = 0; s < WS_U; s++) nxt[s] = (n0 + WS_U + s < nrows) ? load(n0 + WS_U + s) : 0u;  // in flight across the rows below
-#pragma unroll
-        for (int s = 0; s < WS_U; s++) {
-            const int n = n0 + s;
-            if (n < nrows) {                                   // block-uniform
-                if (tid < ROWW) rowbuf[n & 1][tid] = cur[s];
-                asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-                const int m = (int)(reinterpret_cast<uintptr_t>(row_ptr(n)) & 3u);
-                const unsigned char* p = reinterpret_cast<const unsigned char*>(rowbuf[n & 1]) + m + tid * CH;
-                int px[CH], hidx = 0, vidx = 0;
-#pragma unroll
-                for (int c = 0; c < CH; c++) {
-                    px[c] = p[c];
-                    const int dh = px[c] - (int)p[CH + c];
-                    const int dv = prev[c] - px[c];
-                    hidx += dh * dh; vidx += dv * dv;
-                    prev[c] = px[c];
-                }
-                const int i = y0 + n;                          // ROI row of this input row (when n < nrows-1)
-                if (okx) {
-                    if (n < nrows - 1)                         // Chor of this row, FGS.cpp:607-614
-                        ADF_ST(&chor[(size_t)i * g.pw + j], (j == g.rw - 1) ? 0.0f : lookup(hidx));
-                    if (n >= 1) {                              // Cvert of the previous row, FGS.cpp:635-660
-                        // strip-major (ORIENT_STRIP): 16 lanes write one 64-byte piece of the strip's stream
-                        // per row and the following rows complete the line, so plain stores (L2 merges them)
-                        const float v = (i - 1 == g.rh - 1) ? 0.0f : lookup(vidx);
-                        if (strip) cvert[strip_index(i - 1, j, g.rh)] = v;
-                        else ADF_ST(&cvert[(size_t)(i - 1) * g.pw + j], v);
-                    }
-                }
-            }
-        }
-    }
+    __shared__ prep::WsShared<CH> sh;
+    prep::weights_stream_body<CH>(a, blockIdx.x, blockIdx.y, gridDim.y, blockIdx.z, sh, true);
 }
 
 // Row-major [rh][pw] -> transposed [rw][ph] through a 64 x 64 LDS tile, 16-byte accesses on both sides
@@ -272,8 +173,11 @@ hipError_t launch_weights(const WeightArgs& a, int n_pairs, hipStream_t st)
     if (a.chor_orient == ORIENT_N) {   // wave solver: streaming kernel
         dim3 sgrid((a.g.rw + NT - 1) / NT, 1, n_pairs);
         {
+            // a block walks its rows one by one (a workgroup barrier per row, ~0.9 us): rows per block are the kernel's
+            // latency when the call is small, so single frames go down to 4 rows per block (round 3)
             int rpb = 128;
             while (rpb > 16 && ((a.g.rh + rpb - 1) / rpb) * (int)(sgrid.x * sgrid.z) < 2048) rpb >>= 1;
+            while (rpb > 4 && ((a.g.rh + rpb - 1) / rpb) * (int)(sgrid.x * sgrid.z) < 512) rpb >>= 1;
             sgrid.y = (a.g.rh + rpb - 1) / rpb;
         }
         if (a.ch == 1) hipLaunchKernelGGL(weights_stream_kernel<1>, sgrid, dim3(NT), 0, st, a);

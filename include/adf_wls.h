@@ -113,9 +113,11 @@ int adf_wls_get_last_solver(const adf_wls_t* h, int* solver);
 /* Which kernels the confidence stage of the last filter call took (introspection for tests and benchmarks; the
  * results do not depend on it): ADF_PATH_CONF_BAND = computeConfidenceMap (DF.cpp:197-210) ran as the one-sweep band
  * kernel (depth-discontinuity radius 1..8), ADF_PATH_FUSED_FIRST_PASS = the first row pass formed conf*disp itself
- * (DF.cpp:288-290) instead of reading planes a prologue kernel wrote. */
+ * (DF.cpp:288-290) instead of reading planes a prologue kernel wrote, ADF_PATH_MERGED_PREP = the edge weights, the
+ * confidence map and the fill outside the ROI were one launch (calls of at most 2.5 Mpixels of ROI). */
 #define ADF_PATH_CONF_BAND 1
 #define ADF_PATH_FUSED_FIRST_PASS 2
+#define ADF_PATH_MERGED_PREP 4       /* weights + confidence + fill ran as ONE launch (small calls) */
 int adf_wls_get_last_path(const adf_wls_t* h, int* path_flags);
 
 /* DisparityFilter::filter (DF.hpp:75, DF.cpp:219-298) on a batch of n_pairs

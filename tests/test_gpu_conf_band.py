@@ -37,7 +37,8 @@ def _check(adf, oracle, W, H, roi, radius, kind, seed, thresh=24):
     # the kernels under test really ran: the one-sweep confidence kernel and the first row pass that reads its map
     # (ROIs with no more rows than the radius, or narrower than 8 columns, take the column-walking kernels instead)
     band = roi[3] > radius and roi[2] >= 8 and roi[2] > radius
-    assert f.getLastPath() == (adf.PATH_CONF_BAND if band else 0) | adf.PATH_FUSED_FIRST_PASS, f.getLastPath()
+    # (small calls take weights + confidence + fill as ONE launch: the same device code, PATH_MERGED_PREP on top)
+    assert f.getLastPath() & ~adf.PATH_MERGED_PREP == (adf.PATH_CONF_BAND if band else 0) | adf.PATH_FUSED_FIRST_PASS, f.getLastPath()
     got = f.getConfidenceMap()
     assert np.array_equal(got, exp), (W, H, roi, radius, kind, int((got != exp).sum()))
     return f
@@ -185,7 +186,53 @@ def test_filtered_map_on_unaligned_rois(adf, oracle, rx, rw, W, off):
         if solver == adf.SOLVER_EXACT:
             assert d.max() == 0
         else:
-            assert f.getLastPath() == (adf.PATH_CONF_BAND if rw >= 8 else 0) | adf.PATH_FUSED_FIRST_PASS
+            assert f.getLastPath() & ~adf.PATH_MERGED_PREP == (adf.PATH_CONF_BAND if rw >= 8 else 0) | adf.PATH_FUSED_FIRST_PASS
             assert d.max() <= 1 and d.mean() <= 1 / 256.0, (d.max(), d.mean())
             dense = f.filter(torch.from_numpy(dl).cuda(), tv, None, torch.from_numpy(dr).cuda(), roi)
             assert torch.equal(dense, out)
+
+
+@pytest.mark.parametrize("W,H,roi,radius,ch", [(1242, 375, (128, 0, 1114, 375), 2, 1), (1920, 1080, (160, 0, 1760, 1080), 2, 3),
+                                               (640, 480, (71, 7, 562, 466), 5, 3), (300, 40, (3, 1, 290, 37), 4, 1), (100, 9, (0, 0, 100, 9), 1, 3)])
+def test_merged_preparation_launch_equals_the_three_kernels(adf, oracle, W, H, roi, radius, ch):
+    """One small frame per call: edge weights, confidence map and the fill outside the ROI are ONE launch (round 3,
+    single-call latency).  Same device code as the three kernels: confidence, filtered map and the -16 fill must be
+    identical to the ADF_MERGE_SMALL=0 handle's, and equal to the oracle's."""
+    import torch
+    rng = np.random.default_rng(W + H + radius)
+    dl, dr = _maps(rng, H, W, "scene")
+    view = rng.integers(0, 255, (H, W, ch) if ch > 1 else (H, W), dtype=np.uint8)
+    tl, tr, tv = (torch.from_numpy(a).cuda() for a in (dl, dr, view))
+    res = []
+    for flag in ("1", "0"):
+        os.environ["ADF_MERGE_SMALL"] = flag
+        try:
+            f = adf.createDisparityWLSFilterGeneric(True)
+        finally:
+            del os.environ["ADF_MERGE_SMALL"]
+        f.setLambda(8000.0); f.setSigmaColor(1.5); f.setDepthDiscontinuityRadius(radius)
+        out = torch.full((H, W), 1234, dtype=torch.int16, device="cuda")
+        f.filter(tl, tv, out, tr, roi)
+        torch.cuda.synchronize()
+        assert bool(f.getLastPath() & adf.PATH_MERGED_PREP) == (flag == "1")
+        res.append((out.cpu().numpy(), f.getConfidenceMap().cpu().numpy()))
+    assert np.array_equal(res[0][0], res[1][0]) and np.array_equal(res[0][1], res[1][1])
+    p = oracle.default_params(threads=8, use_confidence=1, disc_radius=radius, sigma_color=1.5)
+    p.lambda_ = 8000.0
+    exp, exp_conf = oracle.wls_filter(dl, view, dr, roi, p)
+    assert np.array_equal(res[0][1], exp_conf)
+    d = np.abs(res[0][0].astype(np.int64) - exp.astype(np.int64))
+    assert d.max() <= 1 and d.mean() <= 1 / 256.0
+
+
+def test_batches_keep_the_two_stream_preparation(adf):
+    """Above 2.5 Mpixels of ROI per call the three kernels stay separate launches (two streams overlap them)."""
+    import torch
+    rng = np.random.default_rng(5)
+    n, H, W, roi = 8, 375, 1242, (128, 0, 1114, 375)
+    dl = torch.from_numpy(rng.integers(-100, 2000, (n, H, W)).astype(np.int16)).cuda()
+    view = torch.from_numpy(rng.integers(0, 255, (n, H, W), dtype=np.uint8)).cuda()
+    f = adf.createDisparityWLSFilterGeneric(True)
+    f.setDepthDiscontinuityRadius(2)
+    f.filter(dl, view, None, -dl, roi)
+    assert f.getLastPath() == adf.PATH_CONF_BAND | adf.PATH_FUSED_FIRST_PASS
