@@ -122,7 +122,10 @@ struct Lut {
         for (int i = 0; i < ADF_LUT_LEVELS; i++) host[i] = -expf(-sqrtf((float)i) / s);
         int rc = dev.reserve(sizeof(float) * ADF_LUT_LEVELS, st);
         if (rc) return rc;
-        // synchronous copy: the pageable staging vector dies at scope exit
+        // A change of sigma re-builds the table: kernels of earlier calls on `st` may still read the old one, so the
+        // stream is drained first, and the copy is synchronous because the pageable staging vector dies at scope exit.
+        // Both are host synchronisations: a caller that captures filter calls into a hipGraph must set sigma (and run
+        // one call) BEFORE the capture -- a sigma change between captured calls cannot be captured (include/adf_wls.h).
         HIP_TRY(hipStreamSynchronize(st));
         HIP_TRY(hipMemcpy(dev.p, host.data(), sizeof(float) * ADF_LUT_LEVELS, hipMemcpyHostToDevice));
         sigma = s; valid = true;
@@ -307,6 +310,7 @@ struct adf_wls {
     bool overlap = true;
     bool conf_band = true;   // ADF_CONF_BAND=0: the two-kernel confidence stage (A/B measurements)
     bool merge_small = true; // ADF_MERGE_SMALL=0: never the merged preparation launch (A/B measurements)
+    size_t conf_lds_floor = 0; // ADF_CONF_LDS_FLOOR_KB: see ConfBandArgs::lds_floor (A/B measurements)
     int ensure_side()
     {
         if (side) return ADF_OK;
@@ -338,6 +342,7 @@ extern "C" int adf_wls_create(adf_wls_t** out, int use_confidence, int l, int r,
     if (const char* e = getenv("ADF_NO_OVERLAP")) h->overlap = atoi(e) == 0;   // measurement knob
     if (const char* e = getenv("ADF_CONF_BAND")) h->conf_band = atoi(e) != 0;    // measurement knob
     if (const char* e = getenv("ADF_MERGE_SMALL")) h->merge_small = atoi(e) != 0;   // measurement knob
+    if (const char* e = getenv("ADF_CONF_LDS_FLOOR_KB")) h->conf_lds_floor = (size_t)atoi(e) * 1024;
     *out = h;
     return ADF_OK;
 }
@@ -603,7 +608,7 @@ static int wls_filter_impl(adf_wls_t* h, int n_pairs,
                     HIP_TRY(launch_prep_small(ba, wa, oa, n, st));         // FGS.cpp:163-172 + DF.cpp:197-210 + :284
                 } else if (band) {
                     // both views, LRC and x255 in one band sweep: the right view's map lives in LDS only
-                    ConfBandArgs ba{dL, sL, psL, dRp, sR, psR, confp, g, rrx, thresh, h->disc_radius, h->roll_off, 0};
+                    ConfBandArgs ba{dL, sL, psL, dRp, sR, psR, confp, g, rrx, thresh, h->disc_radius, h->roll_off, 0, fork_weights ? h->conf_lds_floor : 0};
                     ProfScope ps(prof, K_LRC, 8.0 * P, 8.0 * P, st);     // dL 2 + dR 2 read, conf 4 written
                     HIP_TRY(launch_conf_band(ba, n, st));                  // DF.cpp:197-210
                 } else {
@@ -873,6 +878,9 @@ struct adf_fgs {
     Lut lut;
     DevBuf planes; // CH CV D F0 A0 B0
     DevBuf io;     // src / dst image staging
+    // device-guide create: the guide is staged in `io` and the weight kernel is queued on the creator's stream; filter
+    // calls (any stream) overwrite `io` with their source, so they first wait for this event (recorded behind the kernel)
+    hipEvent_t weights_done = nullptr;
 };
 
 // guide_on_device: `guide` is a HIP device pointer (copied into the handle on `st`, no host round trip).
@@ -915,8 +923,13 @@ static int fgs_create_impl(adf_fgs_t** out, const uint8_t* guide, ptrdiff_t gstr
         e = launch_weights(wa, 1, st);
     }
     // host guide: the weights are finished when create returns, like the reference's init (FGS.cpp:163-172);
-    // device guide: they are queued on `st`, the stream the filter calls are expected on
+    // device guide: they are queued on `st`; an event behind them orders every later filter call -- whatever stream it
+    // is on -- after the kernel that still reads the staged guide
     if (e == hipSuccess && !guide_on_device) e = hipStreamSynchronize(st);
+    if (e == hipSuccess && guide_on_device) {
+        e = hipEventCreateWithFlags(&f->weights_done, hipEventDisableTiming);
+        if (e == hipSuccess) e = hipEventRecord(f->weights_done, st);
+    }
     if (e != hipSuccess) { adf_fgs_destroy(f); return fail(ADF_EHIP, "adf_fgs_create: %s", hipGetErrorString(e)); }
     *out = f;
     return ADF_OK;
@@ -942,6 +955,7 @@ extern "C" void adf_fgs_destroy(adf_fgs_t* f)
     if (!f) return;
     DeviceScope ds(f->device);
     f->lut.dev.release(); f->planes.release(); f->io.release();
+    if (f->weights_done) hipEventDestroy(f->weights_done);
     delete f;
 }
 
@@ -999,6 +1013,7 @@ extern "C" int adf_fgs_filter_host(adf_fgs_t* f, const void* src, ptrdiff_t sstr
     if (rc) return rc;
     DeviceScope ds(f->device);
     hipStream_t st = nullptr;
+    if (f->weights_done) HIP_TRY(hipStreamWaitEvent(st, f->weights_done, 0));
     HIP_TRY(hipMemcpy2DAsync(f->io.p, rowb, src, sstride, rowb, f->h, hipMemcpyHostToDevice, st));
     if ((rc = fgs_filter_staged(f, depth, channels, rowb, st))) return rc;
     HIP_TRY(hipMemcpy2DAsync(dst, dstride, f->io.p, rowb, rowb, f->h, hipMemcpyDeviceToHost, st));
@@ -1015,6 +1030,7 @@ extern "C" int adf_fgs_filter_device(adf_fgs_t* f, const void* src, ptrdiff_t ss
     if (rc) return rc;
     DeviceScope ds(f->device);
     hipStream_t st = (hipStream_t)stream;
+    if (f->weights_done) HIP_TRY(hipStreamWaitEvent(st, f->weights_done, 0));
     HIP_TRY(hipMemcpy2DAsync(f->io.p, rowb, src, sstride, rowb, f->h, hipMemcpyDeviceToDevice, st));
     if ((rc = fgs_filter_staged(f, depth, channels, rowb, st))) return rc;
     HIP_TRY(hipMemcpy2DAsync(dst, dstride, f->io.p, rowb, rowb, f->h, hipMemcpyDeviceToDevice, st));

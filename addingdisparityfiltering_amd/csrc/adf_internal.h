@@ -83,6 +83,9 @@ struct ConfBandArgs {
     Geom g; int rrx; int thresh;
     int radius; float roll_off;
     int rows_per_band;
+    // dynamic LDS to ask for at least: above 80 KiB only ONE band workgroup fits a CU, which leaves wave slots for the
+    // weight kernel that runs beside this one on the side stream (0 = just what the kernel needs)
+    size_t lds_floor;
 };
 
 // Non-ROI pixels: filtered map = fill (DF.cpp:284), confidence = 0 (DF.cpp:187-190); either may be null.

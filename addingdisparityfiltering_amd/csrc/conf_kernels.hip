@@ -891,7 +891,8 @@ hipError_t launch_conf_band(const ConfBandArgs& a0, int n_pairs, hipStream_t st)
     if (rpb > a.g.rh) rpb = a.g.rh;
     a.rows_per_band = rpb;
     const dim3 grid((a.g.rh + rpb - 1) / rpb, n_pairs), block(64 * waves);
-    const size_t lds = conf_band_lds(a.g.rw, a.radius);
+    size_t lds = conf_band_lds(a.g.rw, a.radius);
+    if (a.lds_floor > lds) lds = a.lds_floor;         // (occupancy control: see ConfBandArgs::lds_floor)
     // (the attribute belongs to the function ON THE CURRENT DEVICE and a process may hold handles on several: no cache)
 #define ADF_CB(RR)                                                                                          \
     case RR:                                                                                                \

@@ -27,6 +27,26 @@ def test_fgs_device_guide_equals_host_guide(adf, oracle):
             assert np.array_equal(one.cpu().numpy(), host)
         exp = oracle.fgs_filter(guide, flow, 500.0, 1.5, threads=8)
         assert np.array_equal(FastGlobalSmootherFilter(tg, 500.0, 1.5, solver=adf.SOLVER_EXACT).filter(tf).cpu().numpy(), exp)
+    # created on a side stream, filtered from a host array (the legacy stream) and from another stream: the filter
+    # calls must wait for the weight kernel that still reads the staged guide (adf_api.hip fgs_create_impl)
+    guide = rng.integers(0, 255, (h, w, 3), dtype=np.uint8)
+    flow = rng.normal(0, 30, (h, w, 2)).astype(np.float32)
+    host = FastGlobalSmootherFilter(guide, 500.0, 1.5).filter(flow)
+    side, other = torch.cuda.Stream(), torch.cuda.Stream()
+    tg2, tf2 = torch.from_numpy(guide).cuda(), torch.from_numpy(flow).cuda()
+    torch.cuda.synchronize()
+    for _ in range(5):
+        with torch.cuda.stream(side):
+            busy = torch.randn(4096, 4096, device="cuda") @ torch.randn(4096, 4096, device="cuda")   # keeps `side` behind
+            fs = FastGlobalSmootherFilter(tg2, 500.0, 1.5)
+        assert np.array_equal(fs.filter(flow), host)                  # numpy source: adf_fgs_filter_host
+        with torch.cuda.stream(side):
+            fs2 = FastGlobalSmootherFilter(tg2, 500.0, 1.5)
+        with torch.cuda.stream(other):
+            got = fs2.filter(tf2)
+        other.synchronize()
+        assert np.array_equal(got.cpu().numpy(), host)
+        del busy
     # a strided (non-contiguous) device guide is made dense before the call
     big = torch.from_numpy(rng.integers(0, 255, (h, w + 7), dtype=np.uint8)).cuda()
     g2 = big[:, 3:3 + w]

@@ -40,7 +40,7 @@ __device__ __forceinline__ void glds16(const void* gsrc, unsigned lds_dst)
                  : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
 }
 
-enum { F_GLDS = 1, F_LSTORE = 2, F_NOLOAD = 4, F_NOSTORE = 8, F_WINDOW = 16 };   // F_WINDOW: L0 in groups of 8 rows, a wait per group
+enum { F_GLDS = 1, F_LSTORE = 2, F_NOLOAD = 4, F_NOSTORE = 8, F_WINDOW = 16, F_PERSIST = 32 };   // F_WINDOW: L0 in groups of 8 rows, a wait per group
 
 struct Ctx {
     const char* bC; char* b0; unsigned tile_b, strip, h, rbase; int wv, lane, j, p, xp, cidx, r0;
@@ -176,6 +176,81 @@ __global__ void __launch_bounds__(VT) vpat(Args a)
     }
 }
 
+
+// Persistent + software-pipelined: one workgroup per CU walks the strips of all pairs; the stores of strip k's row i are
+// followed at once by the loads of row i of the NEXT strip into the same registers, so the CU never stops streaming
+// (no store tail, no hand-over, no load ramp between strips).  delay: s_sleep(127) repetitions standing in for the solve.
+template <int DELAY>
+__global__ void __launch_bounds__(VT) vpat_persist(Args a, int nstrips_total)
+{
+    const int tid = threadIdx.x;
+    const unsigned xp = tid % XP, cidx = tid / XP, r0 = cidx * M, h = (unsigned)a.h, pitch = (unsigned)a.pitch;
+    const int per_pair = a.pitch / VC;
+    v2f cc[M], f0[M], f1[M];
+    // wave-uniform bases of the current / next strip; per-thread row offsets are strip-independent
+    auto base_u = [&](int s) { return reinterpret_cast<char*>(a.U + 2 * (size_t)(s / per_pair) * a.plane) + (size_t)(s % per_pair) * (2u * VC * TR) * 4u; };
+    auto base_c = [&](int s) { return reinterpret_cast<const char*>(a.C + (size_t)(s / per_pair) * a.plane) + (size_t)(s % per_pair) * h * VC * 4u; };
+    auto rowoff = [&](unsigned row) { return ((row / TR) * (2u * TR * pitch) + (row % TR) * 2u * VC) * 4u + xp * 8u; };
+    int s = blockIdx.x;
+    if (s >= nstrips_total) return;
+    char* bu = base_u(s); const char* bc = base_c(s);
+#pragma unroll
+    for (int i = 0; i < M; i++) {
+        unsigned row = r0 + i; row = row < h ? row : 0u;
+        cc[i] = *reinterpret_cast<const v2f*>(bc + (row * VC + 2u * xp) * 4u);
+        f0[i] = *reinterpret_cast<const v2f*>(bu + rowoff(row));
+        f1[i] = *reinterpret_cast<const v2f*>(bu + rowoff(row) + 4u * VC);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    while (true) {
+#pragma unroll
+        for (int i = 0; i < M; i++) { f0[i] = f0[i] * cc[i] + f1[i]; f1[i] = f1[i] - cc[i]; asm volatile("" : "+v"(f0[i]), "+v"(f1[i])); }
+        __syncthreads();
+        for (int k = 0; k < DELAY; k++) __builtin_amdgcn_s_sleep(127);
+        __syncthreads();
+        const int sn = s + gridDim.x;
+        const bool more = sn < nstrips_total;
+        char* bun = more ? base_u(sn) : bu; const char* bcn = more ? base_c(sn) : bc;
+        unsigned ro = rowoff(r0), co = (r0 * VC + 2u * xp) * 4u;
+        asm volatile("" : "+v"(ro), "+v"(co));
+        const unsigned ro_safe = rowoff(0u), co_safe = (2u * xp) * 4u;
+        const unsigned tile_b = 2u * TR * pitch * 4u;
+#pragma unroll
+        for (int i = 0; i < M; i++) {
+            const bool ok = r0 + i < h;
+            if (ok) {
+                *reinterpret_cast<v2f*>(bu + ro) = f0[i];
+                *reinterpret_cast<v2f*>(bu + ro + 4u * VC) = f1[i];
+            }
+            if (more) {                                      // (workgroup-uniform)
+                const unsigned r2 = ok ? ro : ro_safe;
+                cc[i] = *reinterpret_cast<const v2f*>(bcn + (ok ? co : co_safe));
+                f0[i] = *reinterpret_cast<const v2f*>(bun + r2);
+                f1[i] = *reinterpret_cast<const v2f*>(bun + r2 + 4u * VC);
+            }
+            ro += (((r0 + i + 1u) & (TR - 1u)) == 0u) ? tile_b - (TR - 1u) * (8u * VC) : 8u * VC;
+            co += 4u * VC;
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (!more) break;
+        s = sn; bu = bun; bc = bcn;
+    }
+}
+
+template <int DELAY>
+float run_persist(const Args& a, int pairs, int reps, bool persistent)
+{
+    const int total = (a.pitch / VC) * pairs;
+    dim3 grid(persistent ? 256 : total), block(VT);
+    hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    for (int w = 0; w < 2; w++) hipLaunchKernelGGL(vpat_persist<DELAY>, grid, block, 0, 0, a, total);
+    CK(hipEventRecord(e0));
+    for (int r = 0; r < reps; r++) hipLaunchKernelGGL(vpat_persist<DELAY>, grid, block, 0, 0, a, total);
+    CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1)); CK(hipGetLastError());
+    float ms = 0; CK(hipEventElapsedTime(&ms, e0, e1));
+    return ms / reps;
+}
+
 template <int MODE>
 float run(const Args& a, int pairs, int reps, size_t lds)
 {
@@ -249,6 +324,15 @@ int main(int argc, char** argv)
         {"S0 only", run<F_NOLOAD>(a, pairs, 10, lds), 8 * px},
         {"S1 only", run<F_NOLOAD | F_LSTORE>(a, pairs, 10, lds), 8 * px},
     };
+    if (VC == 16) {
+        struct { const char* name; float ms; } q[] = {
+            {"one workgroup per strip, no solve", run_persist<0>(a, pairs, 10, false)},
+            {"one workgroup per strip, 7 us solve", run_persist<2>(a, pairs, 10, false)},
+            {"persistent + pipelined, no solve", run_persist<0>(a, pairs, 10, true)},
+            {"persistent + pipelined, 7 us solve", run_persist<2>(a, pairs, 10, true)},
+        };
+        for (auto& x : q) printf("  %-40s %8.3f ms  %7.1f GB/s  (x64/pairs: %.3f ms)\n", x.name, x.ms, 20 * px / x.ms / 1e6, x.ms * 64.0 / pairs);
+    }
     printf("column-pass data movement, %d pairs of 3584 x 2160, strips of %d columns, %d chunks of %d rows per workgroup, %d workgroup(s) per strip\n", pairs, VC, CH, M, (a.h + CH * M - 1) / (CH * M));
     for (auto& x : r) printf("  %-32s %8.3f ms  %7.1f GB/s  (x64/pairs: %.3f ms)\n", x.name, x.ms, x.bytes / x.ms / 1e6, x.ms * 64.0 / pairs);
     return 0;
