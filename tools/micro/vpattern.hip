@@ -21,13 +21,19 @@
 #ifndef VCW
 #define VCW 16
 #endif
-constexpr int M = 34, VC = VCW, VT = 512, TR = 2, NS = 12;
+#ifndef VTW
+#define VTW 512
+#endif
+#ifndef NSLOTS
+#define NSLOTS 12
+#endif
+constexpr int M = 34, VC = VCW, VT = VTW, TR = 2, NS = NSLOTS;   // VCW 8 + VTW 256: two independent half-width strips per CU
 constexpr int XP = VC / 2, CH = VT / XP, LPR = VC / 2;   // column pairs, chunks per workgroup, 16-byte pieces per pair-plane row
 constexpr int CPW = 64 / LPR;                            // chunks per wave instruction of the LDS-DMA
 typedef float v2f __attribute__((ext_vector_type(2)));
 typedef float v4f __attribute__((ext_vector_type(4)));
 
-struct Args { float* C; float* U; int pitch, h; size_t plane; };
+struct Args { float* C; float* U; int pitch, h; size_t plane; int delay; };
 
 template <int N> __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" :: "n"(N) : "memory"); }
 __device__ __forceinline__ void wait_lds() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
@@ -107,7 +113,7 @@ __device__ __forceinline__ void glds_prime(const Ctx& c, unsigned pitch, unsigne
 }
 
 template <int MODE>
-__global__ void __launch_bounds__(VT) vpat(Args a)
+__global__ void __launch_bounds__(VT, 2) vpat(Args a)
 {
     extern __shared__ __align__(16) char lds[];
     const int tid = threadIdx.x;
@@ -129,12 +135,19 @@ __global__ void __launch_bounds__(VT) vpat(Args a)
             glds_prime<0, MODE>(c, pitch, ring);
             glds_loop<0, MODE>(c, pitch, ring, ringp, cc, f0, f1);
         } else {
+            // offsets walk down the rows as in the kernel (a 64-bit address or a division per row would cost registers)
+            unsigned vo = line_off(c, (unsigned)c.r0, pitch) + c.xp * 8u, co = ((c.strip * c.h + (unsigned)c.r0) * VC + 2u * c.xp) * 4u;
+            const unsigned vsafe = line_off(c, c.rbase, pitch) + c.xp * 8u, csafe = ((c.strip * c.h + c.rbase) * VC + 2u * c.xp) * 4u;
+            const unsigned tile_b = 2u * TR * pitch * 4u;
 #pragma unroll
             for (int i = 0; i < M; i++) {
-                unsigned row = (unsigned)c.r0 + i; row = row < c.h ? row : c.rbase;
-                cc[i] = *reinterpret_cast<const v2f*>(c.bC + ((c.strip * c.h + row) * VC + 2u * c.xp) * 4u);
-                f0[i] = *reinterpret_cast<const v2f*>(c.b0 + line_off(c, row, pitch) + c.xp * 8u);
-                f1[i] = *reinterpret_cast<const v2f*>(c.b0 + line_off(c, row, pitch) + 4u * VC + c.xp * 8u);
+                const bool ok = (unsigned)c.r0 + i < c.h;
+                const unsigned v = ok ? vo : vsafe;
+                cc[i] = *reinterpret_cast<const v2f*>(c.bC + (ok ? co : csafe));
+                f0[i] = *reinterpret_cast<const v2f*>(c.b0 + v);
+                f1[i] = *reinterpret_cast<const v2f*>(c.b0 + v + 4u * VC);
+                vo += ((((unsigned)c.r0 + i + 1u) & (TR - 1u)) == 0u) ? tile_b - (TR - 1u) * (8u * VC) : 8u * VC;
+                co += 4u * VC;
                 __builtin_amdgcn_sched_barrier(0);
                 if ((MODE & F_WINDOW) && (i & 7) == 7) {
 #pragma unroll
@@ -145,9 +158,17 @@ __global__ void __launch_bounds__(VT) vpat(Args a)
     }
 #pragma unroll
     for (int i = 0; i < M; i++) { f0[i] = f0[i] * cc[i] + f1[i]; f1[i] = f1[i] - cc[i]; asm volatile("" : "+v"(f0[i]), "+v"(f1[i])); }
+    if (a.delay > 0) {   // stands in for the solve: the whole workgroup meets, nothing moves for delay x 0.64 us (s_sleep 127 = 8128 clocks... measured)
+        __syncthreads();
+        for (int k = 0; k < a.delay; k++) __builtin_amdgcn_s_sleep(127);
+        __syncthreads();
+    }
     if (!(MODE & F_NOSTORE)) {
         if (MODE & F_LSTORE) {
             // per wave: rows i of its 8 chunks = 8 whole lines = one 1 KiB image, two slots alternating
+            unsigned lo = line_off(c, (unsigned)c.r0, pitch) + (unsigned)c.p * 16u;   // (lane / LPR is the thread's own chunk)
+            asm volatile("" : "+v"(lo));
+            const unsigned tile_b2 = 2u * TR * pitch * 4u;
 #pragma unroll
             for (int i = 0; i < M; i++) {
                 char* s = ringp + (i & 3) * 1024;
@@ -155,17 +176,20 @@ __global__ void __launch_bounds__(VT) vpat(Args a)
                 *reinterpret_cast<v2f*>(s + c.j * (8 * VC) + 4 * VC + c.xp * 8) = f1[i];
                 wait_lds();
                 const v4f q = *reinterpret_cast<const v4f*>(s + c.lane * 16);
-                const unsigned row = (unsigned)c.r0 + i;
-                if (row < c.h) *reinterpret_cast<v4f*>(c.b0 + line_off(c, row, pitch) + (unsigned)c.p * 16u) = q;
+                if ((unsigned)c.r0 + i < c.h) *reinterpret_cast<v4f*>(c.b0 + lo) = q;
+                lo += ((((unsigned)c.r0 + i + 1u) & (TR - 1u)) == 0u) ? tile_b2 - (TR - 1u) * (8u * VC) : 8u * VC;
             }
         } else {
+            unsigned vo = line_off(c, (unsigned)c.r0, pitch) + c.xp * 8u;
+            asm volatile("" : "+v"(vo));
+            const unsigned tile_b = 2u * TR * pitch * 4u;
 #pragma unroll
             for (int i = 0; i < M; i++) {
-                const unsigned row = (unsigned)c.r0 + i;
-                if (row < c.h) {
-                    *reinterpret_cast<v2f*>(c.b0 + line_off(c, row, pitch) + c.xp * 8u) = f0[i];
-                    *reinterpret_cast<v2f*>(c.b0 + line_off(c, row, pitch) + 4u * VC + c.xp * 8u) = f1[i];
+                if ((unsigned)c.r0 + i < c.h) {
+                    *reinterpret_cast<v2f*>(c.b0 + vo) = f0[i];
+                    *reinterpret_cast<v2f*>(c.b0 + vo + 4u * VC) = f1[i];
                 }
+                vo += ((((unsigned)c.r0 + i + 1u) & (TR - 1u)) == 0u) ? tile_b - (TR - 1u) * (8u * VC) : 8u * VC;
             }
         }
     } else {
@@ -181,7 +205,7 @@ __global__ void __launch_bounds__(VT) vpat(Args a)
 // followed at once by the loads of row i of the NEXT strip into the same registers, so the CU never stops streaming
 // (no store tail, no hand-over, no load ramp between strips).  delay: s_sleep(127) repetitions standing in for the solve.
 template <int DELAY>
-__global__ void __launch_bounds__(VT) vpat_persist(Args a, int nstrips_total)
+__global__ void __launch_bounds__(VT, 2) vpat_persist(Args a, int nstrips_total)
 {
     const int tid = threadIdx.x;
     const unsigned xp = tid % XP, cidx = tid / XP, r0 = cidx * M, h = (unsigned)a.h, pitch = (unsigned)a.pitch;
@@ -241,7 +265,7 @@ template <int DELAY>
 float run_persist(const Args& a, int pairs, int reps, bool persistent)
 {
     const int total = (a.pitch / VC) * pairs;
-    dim3 grid(persistent ? 256 : total), block(VT);
+    dim3 grid(persistent ? 256 * (512 / VT) : total), block(VT);
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     for (int w = 0; w < 2; w++) hipLaunchKernelGGL(vpat_persist<DELAY>, grid, block, 0, 0, a, total);
     CK(hipEventRecord(e0));
@@ -274,11 +298,11 @@ __global__ void fill_kernel(float* p, size_t n, unsigned seed)
 // L1+S1 and every mix must produce exactly what L0+S0 produces on the same data
 static bool verify()
 {
-    Args a; a.pitch = 3584; a.h = 2160; a.plane = (size_t)a.pitch * a.h;
+    Args a; a.pitch = 3584; a.h = 2160; a.plane = (size_t)a.pitch * a.h; a.delay = 0;
     float* U[4];
     CK(hipMalloc(&a.C, a.plane * 4));
     hipLaunchKernelGGL(fill_kernel, dim3((unsigned)((a.plane + 255) / 256)), dim3(256), 0, 0, a.C, a.plane, 7u);
-    const size_t lds = 8 * NS * 1024 + 44 * 1024;
+    const size_t lds = (VT / 64) * NS * 1024 + 44 * 1024 * VC / 16;
     std::vector<float> ref(a.plane * 2), got(a.plane * 2);
     bool ok = true;
     for (int m = 0; m < 4; m++) {
@@ -308,11 +332,11 @@ int main(int argc, char** argv)
 {
     if (!verify()) { printf("VERIFY FAILED\n"); return 1; }
     const int pairs = argc > 1 ? atoi(argv[1]) : 16;
-    Args a; a.pitch = 3584; a.h = 2160; a.plane = (size_t)a.pitch * a.h;
+    Args a; a.pitch = 3584; a.h = 2160; a.plane = (size_t)a.pitch * a.h; a.delay = 0;
     CK(hipMalloc(&a.C, a.plane * 4 * pairs)); CK(hipMalloc(&a.U, a.plane * 8 * pairs));
     CK(hipMemset(a.C, 0, a.plane * 4 * pairs)); CK(hipMemset(a.U, 0, a.plane * 8 * pairs));
     const double px = (double)a.plane * pairs;
-    const size_t lds = 8 * NS * 1024 + 44 * 1024;            // the real kernel's exchange buffers ride along
+    const size_t lds = (VT / 64) * NS * 1024 + 44 * 1024 * VC / 16;   // the real kernel's exchange buffers ride along
     struct { const char* name; float ms; double bytes; } r[] = {
         {"L0+S0 (as the kernel)", run<0>(a, pairs, 10, lds), 20 * px},
         {"L1+S0 (LDS-DMA whole lines)", run<F_GLDS>(a, pairs, 10, lds), 20 * px},
@@ -324,7 +348,7 @@ int main(int argc, char** argv)
         {"S0 only", run<F_NOLOAD>(a, pairs, 10, lds), 8 * px},
         {"S1 only", run<F_NOLOAD | F_LSTORE>(a, pairs, 10, lds), 8 * px},
     };
-    if (VC == 16) {
+    if (VC == 16 || VT == 256) {
         struct { const char* name; float ms; } q[] = {
             {"one workgroup per strip, no solve", run_persist<0>(a, pairs, 10, false)},
             {"one workgroup per strip, 7 us solve", run_persist<2>(a, pairs, 10, false)},
@@ -335,5 +359,11 @@ int main(int argc, char** argv)
     }
     printf("column-pass data movement, %d pairs of 3584 x 2160, strips of %d columns, %d chunks of %d rows per workgroup, %d workgroup(s) per strip\n", pairs, VC, CH, M, (a.h + CH * M - 1) / (CH * M));
     for (auto& x : r) printf("  %-32s %8.3f ms  %7.1f GB/s  (x64/pairs: %.3f ms)\n", x.name, x.ms, x.bytes / x.ms / 1e6, x.ms * 64.0 / pairs);
+    // the same with a stand-in for the solve between loads and stores (workgroup barrier, s_sleep, barrier)
+    for (int d = 1; d <= 8; d *= 2) {
+        a.delay = d;
+        const float t0 = run<0>(a, pairs, 10, lds), t1 = run<F_GLDS>(a, pairs, 10, lds);
+        printf("  solve stand-in %d x s_sleep(127):  L0+S0 %8.3f ms (x64/pairs: %.3f ms)   L1+S0 %8.3f ms (x64/pairs: %.3f ms)\n", d, t0, t0 * 64.0 / pairs, t1, t1 * 64.0 / pairs);
+    }
     return 0;
 }
