@@ -546,18 +546,21 @@ static int wls_filter_impl(adf_wls_t* h, int n_pairs,
             HIP_TRY(hipStreamWaitEvent(h->side, h->ev_fork, 0));
             wst = h->side;
         }
-        if (!merged) {
-            ProfScope ps(prof, K_WEIGHTS, (gch + 8.0) * P, (gch + 8.0) * P, wst);
-            HIP_TRY(launch_weights(wa, n, wst));                           // FGS.cpp:163-172
-        }
         // the fill of everything outside the ROI (DF.cpp:284, :187-190) touches no pixel any other kernel of the call
         // touches: on the wave path it rides the side stream too instead of sitting between the confidence kernel and
-        // the first solve pass (one dependent launch less on the critical path of a single-pair call)
+        // the first solve pass (one dependent launch less on the critical path of a single-pair call) -- and it goes
+        // FIRST there: alone it takes 0.08 ms of a 64 x 4K step on the StereoBM factory's ROI, but queued behind the
+        // weight kernel it starts when the confidence kernel's workgroups hold nearly every register of every CU and
+        // crawls through 0.8 ms as the call's tail (round 3)
         const bool outside_on_side = fork_weights && !conf_given && wave && h->disc_radius <= conf_left_max_radius();
         if (outside_on_side) {
             OutsideArgs oa{o, sO, psO, fill, (float*)h->conf.p + (size_t)first * g.cframe, g};
             ProfScope ps(prof, K_FILL, 6.0 * (F - P), 6.0 * (F - P), wst);
             HIP_TRY(launch_outside(oa, n, wst));
+        }
+        if (!merged) {
+            ProfScope ps(prof, K_WEIGHTS, (gch + 8.0) * P, (gch + 8.0) * P, wst);
+            HIP_TRY(launch_weights(wa, n, wst));                           // FGS.cpp:163-172
         }
         if (fork_weights) HIP_TRY(hipEventRecord(h->ev_join, h->side));
 

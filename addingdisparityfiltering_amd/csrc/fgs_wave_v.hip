@@ -17,9 +17,12 @@ extern "C" int adf_debug_read_vwave(unsigned long long* dst, int n)
 {
     return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(adf_vwave), sizeof(unsigned long long) * (size_t)n);
 }
+#ifndef ADF_V_PHASE_EPI
+#define ADF_V_PHASE_EPI EPI_PLANES   // which pass is stamped (1 = the last pass with the fused epilogue)
+#endif
 #define ADF_WG_ID ((size_t)(((size_t)blockIdx.y * gridDim.x + blockIdx.x) % (1u << 17)))
-#define ADF_STAMP(k) do { if (EPI == EPI_PLANES && threadIdx.x == 0) adf_vphase[ADF_WG_ID * 8 + (k)] = wall_clock64(); } while (0)
-#define ADF_WSTAMP(k) do { if (EPI == EPI_PLANES && (threadIdx.x & 63) == 0) adf_vwave[(ADF_WG_ID * 8 + (threadIdx.x >> 6)) * 2 + (k)] = wall_clock64(); } while (0)
+#define ADF_STAMP(k) do { if (EPI == ADF_V_PHASE_EPI && threadIdx.x == 0) adf_vphase[ADF_WG_ID * 8 + (k)] = wall_clock64(); } while (0)
+#define ADF_WSTAMP(k) do { if (EPI == ADF_V_PHASE_EPI && (threadIdx.x & 63) == 0) adf_vwave[(ADF_WG_ID * 8 + (threadIdx.x >> 6)) * 2 + (k)] = wall_clock64(); } while (0)
 #define ADF_DRAIN() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
 #else
 #define ADF_STAMP(k) do { } while (0)
@@ -130,6 +133,32 @@ __device__ __forceinline__ void v_prime(VLoadCtx& x)
     if constexpr (K < VRing<M>::SLOTS) { v_issue<M, K>(x); v_prime<M, K + 1>(x); }
 }
 
+// saturate_cast<short> of both columns of a thread, packed (low half = first column).  cvRound semantics as sat16() in
+// adf_internal.h: round half to even; NaN and anything outside the int range become INT_MIN and hence -32768; the clamp
+// to [-32768, 32767] is v_cvt_pk_i16_i32's.  EPI_WLS_CONF forms u0 * (1 / (u1 + EPS)) first (DF.cpp:295-296) with
+// v_rcp_f32 + one Newton step instead of the IEEE division's ten instructions: this solver is held to the reference's
+// 1-LSB bar, not to bit identity.  Two things the division did must be kept:
+//  * far from every confident pixel the filtered confidence u1 (and u0 with it) decays into the DENORMAL range while
+//    the ratio stays an ordinary disparity (config 2: thousands of such pixels), and v_rcp_f32 flushes denormal
+//    operands: the denominator is scaled by 2^64 before the reciprocal and the reciprocal by 2^64 after it --
+//    unconditionally (u1 never exceeds a few thousand, so neither product leaves the normal range at the top);
+//  * u1 == 0 exactly: 1 / 1e-43 overflows to +inf -- here 2^64 * rcp(2^64 * 1e-43) does -- and 0 * inf, x * inf and NaN
+//    all leave the int range -> -32768, as in the reference (tests: zero-confidence edge case).
+// (u1 * 2^64 + EPS * 2^64 in one FMA: it differs from (u1 + EPS) * 2^64 only below the last bit of a denormal sum.)
+template <int EPI>
+__device__ __forceinline__ unsigned epi_pack16(v2f u0, v2f u1)
+{
+    v2f x = u0;
+    if (EPI == EPI_WLS_CONF) {
+        const v2f sc = vsplat(0x1p64f);
+        x = u0 * (vrcp_sel<true>(vfma(u1, sc, vsplat(ADF_EPS * 0x1p64f))) * sc);
+    }
+    const bool o0 = !(__builtin_fabsf(x.x) < 2147483648.0f), o1 = !(__builtin_fabsf(x.y) < 2147483648.0f);
+    const int i0 = (int)(o0 ? -32768.0f : __builtin_rintf(x.x)), i1 = (int)(o1 ? -32768.0f : __builtin_rintf(x.y));
+    typedef short s2 __attribute__((ext_vector_type(2)));
+    return __builtin_bit_cast(unsigned, (s2)__builtin_amdgcn_cvt_pk_i16(i0, i1));
+}
+
 template <int M, int R, int EPI>
 __global__ void __launch_bounds__(VT) wave_vpass_kernel(WavePassArgs a)
 {
@@ -153,7 +182,7 @@ __global__ void __launch_bounds__(VT) wave_vpass_kernel(WavePassArgs a)
 #endif
     ADF_STAMP(0); ADF_WSTAMP(0);
 #ifdef ADF_V_PHASE_TIMING
-    if (EPI == EPI_PLANES && threadIdx.x == 0)   // hwreg(HW_REG_XCC_ID) and hwreg(HW_REG_HW_ID), 32 bits each
+    if (EPI == ADF_V_PHASE_EPI && threadIdx.x == 0)   // hwreg(HW_REG_XCC_ID) and hwreg(HW_REG_HW_ID), 32 bits each
         adf_vphase[ADF_WG_ID * 8 + 7] = ((unsigned long long)__builtin_amdgcn_s_getreg(63508) << 32) | (unsigned)__builtin_amdgcn_s_getreg(63492);
 #endif
     // A strip row is a 64-byte half of a 128-byte line of a single right-hand-side plane (R == 1) and a
@@ -313,53 +342,73 @@ __global__ void __launch_bounds__(VT) wave_vpass_kernel(WavePassArgs a)
             voff += ADF_VSTEP(i);
         }
     } else {
+        // (opaque copies made AFTER the solve: nothing of the epilogue's addressing may be formed while the strip
+        // and the sweeps' temporaries fill the register file)
+        int r0e = r0, cole = col;
+        asm volatile("" : "+v"(r0e), "+v"(cole));
         char* ob = reinterpret_cast<char*>(a.out) + (ptrdiff_t)blockIdx.y * a.out_pair_stride +
-                   (ptrdiff_t)(a.out_y0 + r0) * a.out_stride;
+                   (ptrdiff_t)(a.out_y0 + r0e) * a.out_stride;
         const int esz = (EPI == EPI_F32) ? 4 : (EPI == EPI_U8) ? 1 : 2;
-        unsigned ooff = (unsigned)((a.out_x0 + col) * a.out_cn + a.out_c) * (unsigned)esz;
+        unsigned ooff = (unsigned)((a.out_x0 + cole) * a.out_cn + a.out_c) * (unsigned)esz;
+        // Single-channel int16 output with an even number of columns (every call of the disparity filter on an even-width
+        // ROI): both columns of the thread go out as one packed dword -- or, when the ROI starts on an odd column (the
+        // StereoBM factory's ROIs do: DF.cpp:401), as its two halves -- with no per-row alignment test and no branch but
+        // the row mask.  Round 3: the general loop below spent 4.5 us per strip (of 38) on IEEE divisions, conversions
+        // and exec-mask branches (profiles/r03_vphase.txt).  All three conditions are uniform over the launch.
+        const bool fast16 = (EPI == EPI_WLS_CONF || EPI == EPI_I16) && a.out_cn == 1 && (a.nscan & 1) == 0;
+        if (fast16) {
+            const bool al4 = ((reinterpret_cast<uintptr_t>(a.out) | (uintptr_t)a.out_stride | (uintptr_t)a.out_pair_stride) & 3u) == 0 &&
+                             ((a.out_x0 * 2) & 3) == 0;
+            const int hv = (cole < a.nscan ? h : 0) - r0e;        // rows of this thread to store (threads on pitch padding: none)
+            char* dst = ob + ooff;
+            if (al4) {
+#pragma unroll
+                for (int i = 0; i < M; i++) {
+                    const unsigned v = epi_pack16<EPI>(f0[i], f1[i]);
+                    if (i < hv) *reinterpret_cast<unsigned*>(dst) = v;
+                    dst += a.out_stride;
+                    ADF_STEP_FENCE();
+                }
+            } else {
+#pragma unroll
+                for (int i = 0; i < M; i++) {
+                    const unsigned v = epi_pack16<EPI>(f0[i], f1[i]);
+                    if (i < hv) {
+                        reinterpret_cast<uint16_t*>(dst)[0] = (uint16_t)v;
+                        reinterpret_cast<uint16_t*>(dst)[1] = (uint16_t)(v >> 16);
+                    }
+                    dst += a.out_stride;
+                    ADF_STEP_FENCE();
+                }
+            }
+        } else {
 #pragma unroll
         for (int i = 0; i < M; i++) {
             if (r0 + i < h) {
-                if ((EPI == EPI_WLS_CONF || EPI == EPI_I16) && a.out_cn == 1 && col + 1 < a.nscan) {
-                    // both columns of the pair in one 4-byte store (rows are 2-byte aligned only)
-                    int16_t v[2];
 #pragma unroll
-                    for (int e = 0; e < 2; e++) {
+                for (int e = 0; e < 2; e++) {
+                    if (col + e < a.nscan) {
+                        char* dst = ob + ooff + (unsigned)(e * a.out_cn * esz);
                         if (EPI == EPI_WLS_CONF) {
-                            const float rcp = 1.0f / (f1[i][e] + ADF_EPS);                 // DF.cpp:295
-                            v[e] = sat16(f0[i][e] * rcp);                                  // DF.cpp:296
-                        } else
-                            v[e] = sat16(f0[i][e]);
-                    }
-                    char* dst = ob + ooff;
-                    if ((reinterpret_cast<uintptr_t>(dst) & 3u) == 0)
-                        *reinterpret_cast<unsigned*>(dst) = (unsigned)(unsigned short)v[0] | ((unsigned)(unsigned short)v[1] << 16);
-                    else { reinterpret_cast<int16_t*>(dst)[0] = v[0]; reinterpret_cast<int16_t*>(dst)[1] = v[1]; }
-                } else {
+                            const float rcp = 1.0f / (f1[i][e] + ADF_EPS);             // DF.cpp:295
+                            *reinterpret_cast<int16_t*>(dst) = sat16(f0[i][e] * rcp);  // DF.cpp:296
+                        } else {
+                            // generic FGS (FGS.cpp:216-218): with two right-hand sides the second one is
+                            // the next interleaved channel of the same image
 #pragma unroll
-                    for (int e = 0; e < 2; e++) {
-                        if (col + e < a.nscan) {
-                            char* dst = ob + ooff + (unsigned)(e * a.out_cn * esz);
-                            if (EPI == EPI_WLS_CONF) {
-                                const float rcp = 1.0f / (f1[i][e] + ADF_EPS);             // DF.cpp:295
-                                *reinterpret_cast<int16_t*>(dst) = sat16(f0[i][e] * rcp);  // DF.cpp:296
-                            } else {
-                                // generic FGS (FGS.cpp:216-218): with two right-hand sides the second one is
-                                // the next interleaved channel of the same image
-#pragma unroll
-                                for (int r = 0; r < R; r++) {
-                                    const float x = r ? f1[i][e] : f0[i][e];
-                                    char* d = dst + r * esz;
-                                    if (EPI == EPI_I16) *reinterpret_cast<int16_t*>(d) = sat16(x);
-                                    else if (EPI == EPI_U8) *reinterpret_cast<uint8_t*>(d) = sat8(x);
-                                    else *reinterpret_cast<float*>(d) = x;
-                                }
+                            for (int r = 0; r < R; r++) {
+                                const float x = r ? f1[i][e] : f0[i][e];
+                                char* d = dst + r * esz;
+                                if (EPI == EPI_I16) *reinterpret_cast<int16_t*>(d) = sat16(x);
+                                else if (EPI == EPI_U8) *reinterpret_cast<uint8_t*>(d) = sat8(x);
+                                else *reinterpret_cast<float*>(d) = x;
                             }
                         }
                     }
                 }
             }
             ooff += (unsigned)a.out_stride;
+        }
         }
     }
     ADF_STAMP(5); ADF_DRAIN(); ADF_STAMP(6); ADF_WSTAMP(1);

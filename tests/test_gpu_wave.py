@@ -292,3 +292,79 @@ def test_batch_beyond_4gb_workspace(adf, oracle):
     assert np.array_equal(f.getConfidenceMap(n - 1).cpu().numpy(), exp_conf)
     d = np.abs(out[n - 1].cpu().numpy().astype(np.int64) - exp)
     assert d.max() <= MAX_DIF and d.mean() <= MAX_MEAN_DIF, (d.max(), d.mean())
+
+
+def test_zero_confidence_edge_case(adf, oracle):
+    """All-zero confidence: 0 * (1 / (0 + EPS)) is NaN in the reference's arithmetic (DF.cpp:295) and saturate_cast makes
+    it -32768; the packed epilogue of the last column pass (reciprocal + Newton step instead of the division) must end
+    at the same value."""
+    H, W = 20, 48
+    view = np.full((H, W), 100, np.uint8)
+    dr = np.full((H, W), 900, np.int16)
+    # (the disparity that sends every ROI column into the right view's ROI, where the check then fails: DF.cpp:331-338)
+    for roi, d in (((16, 0, 32, 20), 16), ((15, 0, 32, 20), 14), ((15, 1, 31, 18), 13)):   # dword stores / 2-byte stores / general loop
+        dl = np.full((H, W), 16 * d, np.int16)
+        diff, got, exp = _run(adf, oracle, dl, view, dr, roi, disc_radius=1)
+        x, y, w, h = roi
+        assert np.array_equal(got, exp) and np.all(got[y:y + h, x:x + w] == -32768)
+
+
+def test_saturation_extremes(adf, oracle):
+    """Disparities at the int16 limits through the packed epilogue: round-half-even, clamp, out-of-range values."""
+    rng = np.random.default_rng(33)
+    H, W = 64, 128
+    view = rng.integers(0, 255, (H, W, 3), dtype=np.uint8)
+    dl = rng.choice(np.array([-32768, -1, 0, 15, 16, 32767], np.int16), (H, W))
+    dr = rng.choice(np.array([-32768, -16, 0, 1, 32767], np.int16), (H, W))
+    for roi in ((8, 0, 112, 64), (9, 0, 112, 64), (9, 3, 111, 60)):
+        for use_conf in (True, False):
+            diff, got, exp = _run(adf, oracle, dl, view, dr, roi, use_conf, sigma_color=30.0)
+            assert diff.max() <= MAX_DIF, (roi, use_conf, diff.max())
+
+
+@pytest.mark.parametrize("x0", [0, 1, 2, 3])
+@pytest.mark.parametrize("width", [60, 61, 62, 63])
+@pytest.mark.parametrize("row_bytes_extra", [0, 2])
+def test_last_pass_store_paths(adf, oracle, x0, width, row_bytes_extra):
+    """The last column pass writes int16 pairs as dwords when the ROI's first column is even and the output rows are
+    4-byte aligned, as two halves otherwise, and element by element for odd widths: every combination, on device
+    tensors whose row stride is or is not a multiple of 4 bytes."""
+    import torch
+
+    W, H = 70 + row_bytes_extra // 2, 50
+    view, dl, dr, _ = synthetic.make_artificial_example(W, H, 1, seed=5 + x0 + width)
+    roi = (x0, 2, width, 45)
+    p = oracle.default_params(threads=4, sigma_color=2.0, disc_radius=2)
+    exp, exp_conf = oracle.wls_filter(dl, view, dr, roi, p)
+    dev = torch.device("cuda:0")
+    f = adf.createDisparityWLSFilterGeneric(True)
+    f.setSolver(adf.SOLVER_WAVE); f.setSigmaColor(2.0); f.setDepthDiscontinuityRadius(2)
+    out = torch.full((H, W), 12345, dtype=torch.int16, device=dev)
+    got = f.filter(torch.from_numpy(dl).to(dev), torch.from_numpy(view).to(dev), out, torch.from_numpy(dr).to(dev), roi)
+    got = got.cpu().numpy()
+    assert np.array_equal(f.getConfidenceMap().cpu().numpy(), exp_conf)
+    diff = np.abs(got.astype(np.int64) - exp.astype(np.int64))
+    assert diff.max() <= MAX_DIF and diff.mean() <= MAX_MEAN_DIF, (diff.max(), diff.mean())
+    assert np.all(got[:, :x0] == -16) and np.all(got[:, x0 + width:] == -16) and np.all(got[:2] == -16) and np.all(got[47:] == -16)
+
+
+def test_confidence_decaying_into_denormals(adf, oracle):
+    """Far from every confident pixel, behind guide edges, the filtered confidence (and conf * disparity with it) decays
+    below FLT_MIN while their ratio stays an ordinary disparity; the epilogue's reciprocal must not flush such
+    denominators (config 2 has thousands of these pixels; this is the small case of it)."""
+    rng = np.random.default_rng(77)
+    H, W = 48, 320
+    view = (rng.integers(0, 256, (H, W)) // 16 + 100).astype(np.uint8)   # mild noise guide: a gentle decay, many pixels on the way
+    dl = np.full((H, W), 16 * 20, np.int16)
+    dr = np.full((H, W), 3000, np.int16)                                 # left-right inconsistent: confidence 0 ...
+    dr[:, :24] = -16 * 20                                                # ... except where the ROI's first columns look
+    roi = (40, 0, 260, 48)
+    diff, got, exp = _run(adf, oracle, dl, view, dr, roi, **{"lambda": 8000.0, "sigma_color": 1.0, "disc_radius": 2})
+    x, y, w, h = roi
+    # the scene must reach the range the test is about: filtered confidence denormal but its reciprocal still finite
+    conf = oracle.wls_filter(dl, view, dr, roi, oracle.default_params(threads=4, sigma_color=1.0, disc_radius=2))[1]
+    u1 = oracle.fgs_filter(np.ascontiguousarray(view[y:y + h, x:x + w]), np.ascontiguousarray(conf[y:y + h, x:x + w]), 8000.0, 1.0, threads=4)
+    tiny = (u1 >= 2.94e-39) & (u1 < 1.17549435e-38)
+    assert tiny.sum() >= 50, tiny.sum()
+    assert (np.abs(exp[y:y + h, x:x + w][tiny].astype(np.int32) - 320) <= 2).all()
+    assert diff.max() <= MAX_DIF, diff.max()

@@ -33,7 +33,7 @@ constexpr int CPW = 64 / LPR;                            // chunks per wave inst
 typedef float v2f __attribute__((ext_vector_type(2)));
 typedef float v4f __attribute__((ext_vector_type(4)));
 
-struct Args { float* C; float* U; int pitch, h; size_t plane; int delay; };
+struct Args { float* C; float* U; int pitch, h; size_t plane; int delay; short* out; int out_w, out_x0; };
 
 template <int N> __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" :: "n"(N) : "memory"); }
 __device__ __forceinline__ void wait_lds() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
@@ -46,7 +46,10 @@ __device__ __forceinline__ void glds16(const void* gsrc, unsigned lds_dst)
                  : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
 }
 
-enum { F_GLDS = 1, F_LSTORE = 2, F_NOLOAD = 4, F_NOSTORE = 8, F_WINDOW = 16, F_PERSIST = 32 };   // F_WINDOW: L0 in groups of 8 rows, a wait per group
+enum { F_GLDS = 1, F_LSTORE = 2, F_NOLOAD = 4, F_NOSTORE = 8, F_WINDOW = 16, F_PERSIST = 32,
+       F_S16 = 64,      // stores as the LAST pass makes them: int16 row-major, 4 bytes per thread and row = a 32-byte piece per strip row
+       F_S16T = 128,    // int16 into a tiled scratch [4-row tile][strip][4 rows][16 columns]: a strip's 4 rows are one whole 128-byte line
+       F_REMAP = 256 }; // strips b, b+8, b+16, b+24 (same XCD) on four adjacent strips, as the kernel's last pass   // F_WINDOW: L0 in groups of 8 rows, a wait per group
 
 struct Ctx {
     const char* bC; char* b0; unsigned tile_b, strip, h, rbase; int wv, lane, j, p, xp, cidx, r0;
@@ -121,6 +124,10 @@ __global__ void __launch_bounds__(VT, 2) vpat(Args a)
     c.wv = tid >> 6; c.lane = tid & 63; c.j = c.lane / LPR; c.p = c.lane % LPR; c.xp = tid % XP; c.cidx = tid / XP;
     c.rbase = blockIdx.z * (CH * M); c.r0 = (int)c.rbase + c.cidx * M;     // blockIdx.z: which part of the column
     c.strip = blockIdx.x; c.h = (unsigned)a.h;
+    if (MODE & F_REMAP) {
+        const int nfull = (int)(gridDim.x / 32) * 32;
+        if ((int)blockIdx.x < nfull) { const int grp = blockIdx.x >> 5, w = blockIdx.x & 31; c.strip = (unsigned)((grp << 5) + ((w & 7) << 2) + (w >> 3)); }
+    }
     const size_t pb = (size_t)blockIdx.y * a.plane;
     c.bC = reinterpret_cast<const char*>(a.C + pb);
     c.b0 = reinterpret_cast<char*>(a.U + 2 * pb);
@@ -163,7 +170,27 @@ __global__ void __launch_bounds__(VT, 2) vpat(Args a)
         for (int k = 0; k < a.delay; k++) __builtin_amdgcn_s_sleep(127);
         __syncthreads();
     }
-    if (!(MODE & F_NOSTORE)) {
+    if (!(MODE & F_NOSTORE) && (MODE & (F_S16 | F_S16T))) {
+        char* ob = reinterpret_cast<char*>(a.out + (size_t)blockIdx.y * ((size_t)a.out_w * a.h));
+        const unsigned nstrips = (unsigned)a.pitch / VC;
+        unsigned r0s = (unsigned)c.r0;
+        asm volatile("" : "+v"(r0s));   // (the store phase's row arithmetic must not be shared with the load phase's)
+        unsigned o = (MODE & F_S16T) ? ((r0s >> 2) * nstrips + c.strip) * (8u * VC) + (r0s & 3u) * (2u * VC) + 4u * c.xp
+                                     : (r0s * (unsigned)a.out_w + (unsigned)a.out_x0 + c.strip * VC + 2u * c.xp) * 2u;
+        asm volatile("" : "+v"(o));
+#pragma unroll
+        for (int i = 0; i < M; i++) {
+            const unsigned row = r0s + i;
+            if (row < c.h) {
+                const float q0 = f0[i].x * f1[i].x, q1 = f0[i].y * f1[i].y;
+                const unsigned v = ((unsigned)(unsigned short)(short)q0) | ((unsigned)(unsigned short)(short)q1 << 16);
+                *reinterpret_cast<unsigned*>(ob + o) = v;
+            }
+            if (MODE & F_S16T) o += (((row + 1u) & 3u) == 0u) ? nstrips * (8u * VC) - 3u * (2u * VC) : 2u * VC;
+            else o += 2u * (unsigned)a.out_w;
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    } else if (!(MODE & F_NOSTORE)) {
         if (MODE & F_LSTORE) {
             // per wave: rows i of its 8 chunks = 8 whole lines = one 1 KiB image, two slots alternating
             unsigned lo = line_off(c, (unsigned)c.r0, pitch) + (unsigned)c.p * 16u;   // (lane / LPR is the thread's own chunk)
@@ -204,7 +231,7 @@ __global__ void __launch_bounds__(VT, 2) vpat(Args a)
 // Persistent + software-pipelined: one workgroup per CU walks the strips of all pairs; the stores of strip k's row i are
 // followed at once by the loads of row i of the NEXT strip into the same registers, so the CU never stops streaming
 // (no store tail, no hand-over, no load ramp between strips).  delay: s_sleep(127) repetitions standing in for the solve.
-template <int DELAY>
+template <int DELAY, bool S16 = false>
 __global__ void __launch_bounds__(VT, 2) vpat_persist(Args a, int nstrips_total)
 {
     const int tid = threadIdx.x;
@@ -215,7 +242,10 @@ __global__ void __launch_bounds__(VT, 2) vpat_persist(Args a, int nstrips_total)
     auto base_u = [&](int s) { return reinterpret_cast<char*>(a.U + 2 * (size_t)(s / per_pair) * a.plane) + (size_t)(s % per_pair) * (2u * VC * TR) * 4u; };
     auto base_c = [&](int s) { return reinterpret_cast<const char*>(a.C + (size_t)(s / per_pair) * a.plane) + (size_t)(s % per_pair) * h * VC * 4u; };
     auto rowoff = [&](unsigned row) { return ((row / TR) * (2u * TR * pitch) + (row % TR) * 2u * VC) * 4u + xp * 8u; };
-    int s = blockIdx.x;
+    // S16 (the last pass): four adjacent strips share the 128-byte lines of the int16 output, so they go to blocks with
+    // equal blockIdx % 8 (one XCD under round-robin placement; speed only) in the same iteration
+    const int bmap = S16 ? ((((int)blockIdx.x >> 5) * 8 + ((int)blockIdx.x & 7)) * 4 + (((int)blockIdx.x >> 3) & 3)) : (int)blockIdx.x;
+    int s = (gridDim.x == 256u) ? bmap : (int)blockIdx.x;
     if (s >= nstrips_total) return;
     char* bu = base_u(s); const char* bc = base_c(s);
 #pragma unroll
@@ -239,6 +269,38 @@ __global__ void __launch_bounds__(VT, 2) vpat_persist(Args a, int nstrips_total)
         asm volatile("" : "+v"(ro), "+v"(co));
         const unsigned ro_safe = rowoff(0u), co_safe = (2u * xp) * 4u;
         const unsigned tile_b = 2u * TR * pitch * 4u;
+        if (S16) {
+            // results packed to int16 pairs first: the strip's 3 x M register pairs are free for the next strip's loads,
+            // which are issued row by row in front of the (small) stores
+            unsigned pk[M];
+#pragma unroll
+            for (int i = 0; i < M; i++) {
+                const float q0 = f0[i].x * f1[i].x, q1 = f0[i].y * f1[i].y;
+                pk[i] = ((unsigned)(unsigned short)(short)q0) | ((unsigned)(unsigned short)(short)q1 << 16);
+            }
+            char* ob = reinterpret_cast<char*>(a.out + (size_t)(s / per_pair) * ((size_t)a.out_w * a.h));
+            unsigned oo = (r0 * (unsigned)a.out_w + (unsigned)a.out_x0 + (unsigned)(s % per_pair) * VC + 2u * xp) * 2u;
+            if (!more) {                                     // last strip of this workgroup: stores only
+#pragma unroll
+                for (int i = 0; i < M; i++) {
+                    if (r0 + i < h) *reinterpret_cast<unsigned*>(ob + oo) = pk[i];
+                    oo += 2u * (unsigned)a.out_w;
+                }
+                break;
+            }
+#pragma unroll
+            for (int i = 0; i < M; i++) {
+                const bool ok = r0 + i < h;
+                const unsigned r2 = ok ? ro : ro_safe;
+                cc[i] = *reinterpret_cast<const v2f*>(bcn + (ok ? co : co_safe));
+                f0[i] = *reinterpret_cast<const v2f*>(bun + r2);
+                f1[i] = *reinterpret_cast<const v2f*>(bun + r2 + 4u * VC);
+                if (ok) *reinterpret_cast<unsigned*>(ob + oo) = pk[i];
+                ro += (((r0 + i + 1u) & (TR - 1u)) == 0u) ? tile_b - (TR - 1u) * (8u * VC) : 8u * VC;
+                co += 4u * VC; oo += 2u * (unsigned)a.out_w;
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        } else {
 #pragma unroll
         for (int i = 0; i < M; i++) {
             const bool ok = r0 + i < h;
@@ -256,20 +318,21 @@ __global__ void __launch_bounds__(VT, 2) vpat_persist(Args a, int nstrips_total)
             co += 4u * VC;
             __builtin_amdgcn_sched_barrier(0);
         }
+        }
         if (!more) break;
         s = sn; bu = bun; bc = bcn;
     }
 }
 
-template <int DELAY>
+template <int DELAY, bool S16 = false>
 float run_persist(const Args& a, int pairs, int reps, bool persistent)
 {
     const int total = (a.pitch / VC) * pairs;
     dim3 grid(persistent ? 256 * (512 / VT) : total), block(VT);
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
-    for (int w = 0; w < 2; w++) hipLaunchKernelGGL(vpat_persist<DELAY>, grid, block, 0, 0, a, total);
+    for (int w = 0; w < 2; w++) hipLaunchKernelGGL((vpat_persist<DELAY, S16>), grid, block, 0, 0, a, total);
     CK(hipEventRecord(e0));
-    for (int r = 0; r < reps; r++) hipLaunchKernelGGL(vpat_persist<DELAY>, grid, block, 0, 0, a, total);
+    for (int r = 0; r < reps; r++) hipLaunchKernelGGL((vpat_persist<DELAY, S16>), grid, block, 0, 0, a, total);
     CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1)); CK(hipGetLastError());
     float ms = 0; CK(hipEventElapsedTime(&ms, e0, e1));
     return ms / reps;
@@ -298,7 +361,7 @@ __global__ void fill_kernel(float* p, size_t n, unsigned seed)
 // L1+S1 and every mix must produce exactly what L0+S0 produces on the same data
 static bool verify()
 {
-    Args a; a.pitch = 3584; a.h = 2160; a.plane = (size_t)a.pitch * a.h; a.delay = 0;
+    Args a; a.pitch = 3584; a.h = 2160; a.plane = (size_t)a.pitch * a.h; a.delay = 0; a.out = nullptr; a.out_w = 3840; a.out_x0 = 256;
     float* U[4];
     CK(hipMalloc(&a.C, a.plane * 4));
     hipLaunchKernelGGL(fill_kernel, dim3((unsigned)((a.plane + 255) / 256)), dim3(256), 0, 0, a.C, a.plane, 7u);
@@ -334,6 +397,7 @@ int main(int argc, char** argv)
     const int pairs = argc > 1 ? atoi(argv[1]) : 16;
     Args a; a.pitch = 3584; a.h = 2160; a.plane = (size_t)a.pitch * a.h; a.delay = 0;
     CK(hipMalloc(&a.C, a.plane * 4 * pairs)); CK(hipMalloc(&a.U, a.plane * 8 * pairs));
+    a.out_w = 3840; a.out_x0 = 256; CK(hipMalloc(&a.out, (size_t)a.out_w * a.h * 2 * pairs));
     CK(hipMemset(a.C, 0, a.plane * 4 * pairs)); CK(hipMemset(a.U, 0, a.plane * 8 * pairs));
     const double px = (double)a.plane * pairs;
     const size_t lds = (VT / 64) * NS * 1024 + 44 * 1024 * VC / 16;   // the real kernel's exchange buffers ride along
@@ -347,6 +411,12 @@ int main(int argc, char** argv)
         {"L1 only", run<F_GLDS | F_NOSTORE>(a, pairs, 10, lds), 12 * px},
         {"S0 only", run<F_NOLOAD>(a, pairs, 10, lds), 8 * px},
         {"S1 only", run<F_NOLOAD | F_LSTORE>(a, pairs, 10, lds), 8 * px},
+        {"L0+S16 (last pass: int16 rows)", run<F_S16>(a, pairs, 10, lds), 14 * px},
+        {"L0+S16 remapped strips", run<F_S16 | F_REMAP>(a, pairs, 10, lds), 14 * px},
+        {"L0+S16T (int16, tiled lines)", run<F_S16T>(a, pairs, 10, lds), 14 * px},
+        {"S16 only", run<F_S16 | F_NOLOAD>(a, pairs, 10, lds), 2 * px},
+        {"S16 only, remapped strips", run<F_S16 | F_REMAP | F_NOLOAD>(a, pairs, 10, lds), 2 * px},
+        {"S16T only", run<F_S16T | F_NOLOAD>(a, pairs, 10, lds), 2 * px},
     };
     if (VC == 16 || VT == 256) {
         struct { const char* name; float ms; } q[] = {
@@ -355,6 +425,15 @@ int main(int argc, char** argv)
             {"persistent + pipelined, no solve", run_persist<0>(a, pairs, 10, true)},
             {"persistent + pipelined, 7 us solve", run_persist<2>(a, pairs, 10, true)},
         };
+        a.delay = 2;
+        const float l0 = run<F_S16 | F_REMAP>(a, pairs, 10, lds);
+        a.delay = 0;
+        struct { const char* name; float ms; } q16[] = {
+            {"last pass (int16 rows): one workgroup per strip, 7 us solve", l0},
+            {"last pass: persistent, next strip's loads before the stores, no solve", run_persist<0, true>(a, pairs, 10, true)},
+            {"last pass: persistent, next strip's loads before the stores, 7 us solve", run_persist<2, true>(a, pairs, 10, true)},
+        };
+        for (auto& x : q16) printf("  %-72s %8.3f ms  (x64/pairs: %.3f ms)\n", x.name, x.ms, x.ms * 64.0 / pairs);
         for (auto& x : q) printf("  %-40s %8.3f ms  %7.1f GB/s  (x64/pairs: %.3f ms)\n", x.name, x.ms, 20 * px / x.ms / 1e6, x.ms * 64.0 / pairs);
     }
     printf("column-pass data movement, %d pairs of 3584 x 2160, strips of %d columns, %d chunks of %d rows per workgroup, %d workgroup(s) per strip\n", pairs, VC, CH, M, (a.h + CH * M - 1) / (CH * M));
