@@ -537,7 +537,7 @@ static int wls_filter_impl(adf_wls_t* h, int n_pairs,
         // maps only -- one is bound by memory latency, the others lean on the vector ALUs -- so the weight
         // kernel is forked onto the side stream and joined before the first solve pass
         // one small frame per call: weights, confidence map and fill in ONE launch on the caller's stream (no fork)
-        const bool merged = band && h->merge_small && prep_small_fits(g, h->disc_radius, gch, n);
+        const bool merged = band && h->merge_small && prep_small_fits(g, h->disc_radius, gch, n) && prep_small_guide_fits(g, sG, gch);
         const bool fork_weights = conf && h->overlap && !merged;
         hipStream_t wst = st;
         if (fork_weights) {

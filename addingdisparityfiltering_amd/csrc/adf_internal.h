@@ -178,6 +178,7 @@ hipError_t launch_outside(const OutsideArgs& a, int n_pairs, hipStream_t st);
 bool conf_band_fits(const Geom& g, int radius);                                 // geometry / radius the band kernel covers
 hipError_t launch_conf_band(const ConfBandArgs& a, int n_pairs, hipStream_t st);
 // weights + confidence map + outside fill in one launch, for calls small enough to be latency-bound (conf_kernels.hip)
+bool prep_small_guide_fits(const Geom& g, ptrdiff_t guide_stride, int channels);
 bool prep_small_fits(const Geom& g, int radius, int channels, int n_pairs);
 hipError_t launch_prep_small(const ConfBandArgs& c, const WeightArgs& w, const OutsideArgs& o, int n_pairs, hipStream_t st);
 int conf_left_max_radius();

@@ -915,15 +915,23 @@ bool prep_small_fits(const Geom& g, int radius, int channels, int n_pairs)
            (double)g.rw * g.rh * n_pairs <= 2.5e6;
 }
 
+// (the weight role reads the guide through a 32-bit buffer descriptor per block: prep_bodies.h)
+bool prep_small_guide_fits(const Geom& g, ptrdiff_t guide_stride, int channels)
+{
+    return guide_stride > 0 && (size_t)(g.rh + 1) * (size_t)guide_stride < ((size_t)1 << 30) && (size_t)g.W * channels < ((size_t)1 << 29);
+}
+
 hipError_t launch_prep_small(const ConfBandArgs& c0, const WeightArgs& w, const OutsideArgs& o, int n_pairs, hipStream_t st)
 {
     if (!prep_small_fits(c0.g, c0.radius, w.ch, n_pairs)) return hipErrorInvalidValue;
     if (!(w.chor_orient == ORIENT_N && w.cvert_orient == ORIENT_STRIP)) return hipErrorInvalidValue;
+    if (!prep_small_guide_fits(c0.g, w.stride, w.ch)) return hipErrorInvalidValue;
     PrepArgs a{};
     a.c = c0; a.w = w; a.o = o;
     const Geom& g = c0.g;
     int waves = (g.rw + CB_WOUT(c0.radius) - 1) / CB_WOUT(c0.radius);
     if (waves < prep::WS_NT / 64) waves = prep::WS_NT / 64;
+    if (waves < NT / 64) waves = NT / 64;                  // (the fill role works in blocks of NT threads)
     // short bands and few rows per weight block: every role is walked row by row, a barrier per row
     // (as short as the halo allows while that still leaves no more than about one band per CU, and about two weight
     // blocks per CU: beyond that the roles only queue behind each other)
@@ -933,7 +941,7 @@ hipError_t launch_prep_small(const ConfBandArgs& c0, const WeightArgs& w, const 
     if (rpb > g.rh) rpb = g.rh;
     a.c.rows_per_band = rpb;
     a.nC = (g.rh + rpb - 1) / rpb;
-    a.nWx = (g.rw + prep::WS_NT - 1) / prep::WS_NT;
+    a.nWx = (g.rw + prep::WS_BCOLS - 1) / prep::WS_BCOLS;
     int wrows = (rows_all * a.nWx + 511) / 512;
     if (wrows < 4) wrows = 4;
     a.nWy = (g.rh + wrows - 1) / wrows;

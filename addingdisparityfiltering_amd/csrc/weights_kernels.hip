@@ -105,7 +105,7 @@ __global__ void __launch_bounds__(NT) weights_kernel(WeightArgs a)
         const float v = (i == g.rh - 1) ? 0.0f : wv[kk];   // FGS.cpp:658-660
         if (a.chor_orient == ORIENT_N) { if (ok) chor[(size_t)i * g.pw + j] = h; }
         else th[tx * (TY + 1) + r] = ok ? h : 0.0f;
-        if (ok) cvert[(size_t)i * g.pw + j] = v;           // Cvert is consumed row-major by both solvers
+        if (ok) cvert[a.cvert_orient == ORIENT_STRIP ? strip_index(i, j, g.rh) : (size_t)i * g.pw + j] = v;   // row-major, or the wave solver's strips
     }
     if (a.chor_orient == ORIENT_T) {
         __syncthreads();
@@ -121,7 +121,7 @@ __global__ void __launch_bounds__(NT) weights_kernel(WeightArgs a)
 // Row-major outputs (wave solver): the column-walking streaming kernel; its body is shared with the merged preparation
 // kernel of conf_kernels.hip (prep_bodies.h).
 template <int CH>
-__global__ void __launch_bounds__(NT) weights_stream_kernel(WeightArgs a)
+__global__ void __launch_bounds__(prep::WS_NT) weights_stream_kernel(WeightArgs a)
 {
     __shared__ prep::WsShared<CH> sh;
     prep::weights_stream_body<CH>(a, blockIdx.x, blockIdx.y, gridDim.y, blockIdx.z, sh, true);
@@ -170,18 +170,21 @@ hipError_t launch_weights(const WeightArgs& a, int n_pairs, hipStream_t st)
         return hipGetLastError();
     }
     if (a.cvert_orient != ORIENT_N && !(a.cvert_orient == ORIENT_STRIP && a.chor_orient == ORIENT_N)) return hipErrorInvalidValue;
-    if (a.chor_orient == ORIENT_N) {   // wave solver: streaming kernel
-        dim3 sgrid((a.g.rw + NT - 1) / NT, 1, n_pairs);
+    // row-major Chor: the streaming kernel -- unless a block's slice of the guide cannot be put behind one 32-bit buffer
+    // descriptor (row strides of a gigabyte: the generic tile kernel below takes those)
+    if (a.chor_orient == ORIENT_N && a.stride > 0 && a.stride < ((ptrdiff_t)1 << 29) && (size_t)a.g.W * a.ch < ((size_t)1 << 29)) {
+        dim3 sgrid((a.g.rw + prep::WS_BCOLS - 1) / prep::WS_BCOLS, 1, n_pairs);
         {
-            // a block walks its rows one by one (a workgroup barrier per row, ~0.9 us): rows per block are the kernel's
-            // latency when the call is small, so single frames go down to 4 rows per block (round 3)
+            // rows per block: tall blocks amortise the table load and the extra row; enough blocks for the chip; and few
+            // enough rows that a block's slice of the guide stays inside one descriptor (prep_bodies.h)
             int rpb = 128;
             while (rpb > 16 && ((a.g.rh + rpb - 1) / rpb) * (int)(sgrid.x * sgrid.z) < 2048) rpb >>= 1;
             while (rpb > 4 && ((a.g.rh + rpb - 1) / rpb) * (int)(sgrid.x * sgrid.z) < 512) rpb >>= 1;
+            while (rpb > 1 && (size_t)(rpb + 1) * (size_t)a.stride >= ((size_t)1 << 30)) rpb >>= 1;
             sgrid.y = (a.g.rh + rpb - 1) / rpb;
         }
-        if (a.ch == 1) hipLaunchKernelGGL(weights_stream_kernel<1>, sgrid, dim3(NT), 0, st, a);
-        else if (a.ch == 3) hipLaunchKernelGGL(weights_stream_kernel<3>, sgrid, dim3(NT), 0, st, a);
+        if (a.ch == 1) hipLaunchKernelGGL(weights_stream_kernel<1>, sgrid, dim3(prep::WS_NT), 0, st, a);
+        else if (a.ch == 3) hipLaunchKernelGGL(weights_stream_kernel<3>, sgrid, dim3(prep::WS_NT), 0, st, a);
         else return hipErrorInvalidValue;
         return hipGetLastError();
     }

@@ -1,0 +1,86 @@
+"""GPU tests aimed at the edge-weight kernel (FGS.cpp:586-661): four columns per lane, the guide read as aligned
+windows through a range-checked buffer descriptor, packed-byte dot products.  A wrong weight anywhere changes the
+exact solver's int16 output (bit-exact against the oracle), so the filter itself is the probe: guides at every byte
+misalignment, as views into wider images, with widths that leave partial lanes / partial dwords at the row end,
+ROIs touching the right and bottom edge of an exactly sized buffer, strong edges (table indices beyond the head
+cached in LDS), one and three channels; the wave solver reads the same weights through its strip-major layout."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _guide(rng, H, W, ch, edges):
+    g = rng.integers(90, 110, (H, W, ch)).astype(np.int32)
+    if edges:                                   # strong edges: squared distances far beyond 2048
+        g[:, W // 3:] += 120
+        g[H // 2:, :] -= 80
+        g[rng.integers(0, H, 40), rng.integers(0, W, 40)] = 255
+    g = np.clip(g, 0, 255).astype(np.uint8)
+    return g if ch == 3 else g[:, :, 0]
+
+
+def _on_device(torch, arr, byte_shift, wide):
+    """arr as a CUDA tensor whose storage starts `byte_shift` bytes into an allocation, optionally as a view into a wider image."""
+    dev = torch.device("cuda:0")
+    H, W = arr.shape[:2]
+    ch = 1 if arr.ndim == 2 else arr.shape[2]
+    Wb = W + 11 if wide else W
+    buf = torch.zeros(H * Wb * ch + 8, dtype=torch.uint8, device=dev)
+    big = buf[byte_shift:byte_shift + H * Wb * ch].view(H, Wb, ch)
+    x0 = 5 if wide else 0
+    view = big[:, x0:x0 + W]
+    view.copy_(torch.from_numpy(arr.reshape(H, W, ch)).to(dev))
+    assert view.data_ptr() % 4 == (buf.data_ptr() + byte_shift + x0 * ch) % 4
+    return view if ch == 3 else view[:, :, 0]
+
+
+@pytest.mark.parametrize("ch", [1, 3])
+@pytest.mark.parametrize("byte_shift", [0, 1, 2, 3])
+@pytest.mark.parametrize("wide", [False, True])
+def test_weights_at_every_misalignment(adf, oracle, ch, byte_shift, wide):
+    import torch
+
+    rng = np.random.default_rng(100 + 10 * ch + byte_shift)
+    H, W = 37, 523                               # two blocks of 512 columns, a partial lane, W * ch not a multiple of 4
+    guide = _guide(rng, H, W, ch, edges=True)
+    disp = (rng.integers(0, 64, (H, W)) * 16).astype(np.int16)
+    dev_guide = _on_device(torch, guide, byte_shift, wide)
+    for roi in ((0, 0, W, H), (7, 3, W - 7, H - 3), (2, 0, 511, H), (5, 1, 512, 30)):
+        p = oracle.default_params(threads=4, use_confidence=0, sigma_color=9.0)
+        p.lambda_ = 500.0
+        exp, _ = oracle.wls_filter(disp, guide, None, roi, p)
+        for solver, tol in ((adf.SOLVER_EXACT, 0), (adf.SOLVER_WAVE, 1)):
+            f = adf.createDisparityWLSFilterGeneric(False)
+            f.setSolver(solver); f.setLambda(500.0); f.setSigmaColor(9.0)
+            got = f.filter(torch.from_numpy(disp).to(dev_guide.device), dev_guide, None, None, roi).cpu().numpy()
+            d = np.abs(got.astype(np.int32) - exp.astype(np.int32)).max()
+            assert d <= tol, (roi, solver, d)
+
+
+@pytest.mark.parametrize("ch", [1, 3])
+@pytest.mark.parametrize("W", [4, 5, 9, 64, 130, 1030])
+def test_weights_widths_and_tiny_images(adf, oracle, ch, W):
+    rng = np.random.default_rng(7 * W + ch)
+    H = 9
+    guide = _guide(rng, H, W, ch, edges=W > 8)
+    disp = (rng.integers(0, 64, (H, W)) * 16).astype(np.int16)
+    roi = (0, 0, W, H)
+    p = oracle.default_params(threads=2, use_confidence=0, sigma_color=4.0)
+    exp, _ = oracle.wls_filter(disp, guide, None, roi, p)
+    f = adf.createDisparityWLSFilterGeneric(False)
+    f.setSolver(adf.SOLVER_EXACT); f.setSigmaColor(4.0)
+    got = f.filter(disp, guide, None, None, roi)
+    assert np.array_equal(got, exp)
+
+
+def test_generic_fgs_weights_bit_exact_with_strong_edges(adf, oracle):
+    """FastGlobalSmootherFilter on float data: the planes themselves (no int16 rounding in between)."""
+    rng = np.random.default_rng(5)
+    H, W = 70, 600
+    guide = _guide(rng, H, W, 3, edges=True)
+    src = rng.normal(0, 50, (H, W)).astype(np.float32)
+    exp = oracle.fgs_filter(guide, src, 300.0, 12.0, threads=4)
+    f = adf.createFastGlobalSmootherFilter(guide, 300.0, 12.0, solver=adf.SOLVER_EXACT)
+    got = f.filter(src)
+    assert np.array_equal(np.asarray(got), exp)
