@@ -31,7 +31,7 @@ namespace prep {
 // there instead of touching memory the caller never promised.
 // ---------------------------------------------------------------------------------------
 #ifndef ADF_WS_GROUP
-#define ADF_WS_GROUP 8
+#define ADF_WS_GROUP 4
 #endif
 constexpr int WS_U = ADF_WS_GROUP;             // rows in flight per lane (prefetch group)
 constexpr int WS_NT = 128;                     // threads of a block of the streaming weight kernel
@@ -51,6 +51,172 @@ typedef float ws_v4f __attribute__((ext_vector_type(4)));
 template <int CH> struct WsWin;                                   // a lane's raw window of one row
 template <> struct WsWin<3> { ws_v4u a; unsigned b; };
 template <> struct WsWin<1> { ws_v2u a; };
+template <int CH> struct WsPrev { unsigned q[WS_COLS], qa[WS_COLS]; };   // the lane's pixels of the previous row (CH == 1: q[0] = four bytes) and their a.a
+
+// Descriptor over `rows` image rows of `row_bytes` valid bytes each starting at `base0` (any alignment): the base is
+// aligned down to a dword (`mis` = bytes skipped) and the record count rounded up to one, so that every byte a window
+// may legitimately want lies inside an in-range aligned dword.  All inputs must be uniform; they are said to be so.
+struct WsGuide {
+    __amdgpu_buffer_rsrc_t rsrc; unsigned mis, stride;
+};
+__device__ __forceinline__ WsGuide ws_guide(uintptr_t base0, ptrdiff_t stride_bytes, int rows, int row_bytes)
+{
+    WsGuide gd;
+    gd.mis = (unsigned)__builtin_amdgcn_readfirstlane((int)(base0 & 3u));
+    const unsigned blo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)((base0 - gd.mis) & 0xffffffffu));
+    const unsigned bhi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)((base0 - gd.mis) >> 32));
+    gd.stride = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)stride_bytes);
+    const unsigned records = (unsigned)__builtin_amdgcn_readfirstlane(
+        (int)((gd.mis + (unsigned)(rows - 1) * gd.stride + (unsigned)row_bytes + 3u) & ~3u));
+    gd.rsrc = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void*>((uintptr_t)blo | ((uintptr_t)bhi << 32)), (short)0, (int)records, 0x00020000);
+    return gd;
+}
+
+// the lane's window of a row: `wo` = byte offset (from the descriptor's base) of the aligned dword holding the lane's first pixel
+template <int CH>
+__device__ __forceinline__ WsWin<CH> ws_load(const WsGuide& gd, unsigned wo)
+{
+    WsWin<CH> w;
+    if constexpr (CH == 3) {
+        w.a = __builtin_amdgcn_raw_buffer_load_b128(gd.rsrc, wo, 0, 0);
+        w.b = __builtin_amdgcn_raw_buffer_load_b32(gd.rsrc, wo + 16u, 0, 0);
+    } else {
+        w.a = __builtin_amdgcn_raw_buffer_load_b64(gd.rsrc, wo, 0, 0);
+    }
+    return w;
+}
+
+// Table indices of a lane's four pixels in one row: hidx[k] = |pixel k - pixel k+1|^2 (FGS.cpp:607-612), vidx[k] =
+// |previous row's pixel k - pixel k|^2 (FGS.cpp:640-653); m = bytes the window starts before the first pixel.
+template <int CH>
+__device__ __forceinline__ void ws_indices(const WsWin<CH>& w, unsigned m, WsPrev<CH>& pv, int (&hidx)[WS_COLS], int (&vidx)[WS_COLS])
+{
+    if constexpr (CH == 3) {
+        const unsigned e0 = __builtin_amdgcn_alignbyte(w.a.y, w.a.x, m), e1 = __builtin_amdgcn_alignbyte(w.a.z, w.a.y, m);
+        const unsigned e2 = __builtin_amdgcn_alignbyte(w.a.w, w.a.z, m), e3 = __builtin_amdgcn_alignbyte(w.b, w.a.w, m);
+        unsigned p[WS_COLS + 1], pa[WS_COLS + 1];              // pixels as [c0 c1 c2 0], and a.a
+        p[0] = e0 & 0x00ffffffu;
+        p[1] = __builtin_amdgcn_perm(e1, e0, 0x0c050403u);
+        p[2] = __builtin_amdgcn_perm(e2, e1, 0x0c040302u);
+        p[3] = e2 >> 8;
+        p[4] = e3 & 0x00ffffffu;
+#pragma unroll
+        for (int k = 0; k <= WS_COLS; k++) pa[k] = __builtin_amdgcn_udot4(p[k], p[k], 0u, false);
+#pragma unroll
+        for (int k = 0; k < WS_COLS; k++) {
+            hidx[k] = (int)(pa[k] + pa[k + 1]) - 2 * (int)__builtin_amdgcn_udot4(p[k], p[k + 1], 0u, false);
+            vidx[k] = (int)(pa[k] + pv.qa[k]) - 2 * (int)__builtin_amdgcn_udot4(p[k], pv.q[k], 0u, false);
+            pv.q[k] = p[k]; pv.qa[k] = pa[k];
+        }
+    } else {
+        const unsigned e = __builtin_amdgcn_alignbyte(w.a.y, w.a.x, m);
+        const unsigned nb = __builtin_amdgcn_alignbyte(0u, w.a.y, m) & 0xffu;
+#pragma unroll
+        for (int k = 0; k < WS_COLS; k++) {
+            const int v = (int)((e >> (8 * k)) & 0xffu);
+            const int r = k < WS_COLS - 1 ? (int)((e >> (8 * k + 8)) & 0xffu) : (int)nb;
+            const int u = (int)((pv.q[0] >> (8 * k)) & 0xffu);
+            hidx[k] = (v - r) * (v - r);
+            vidx[k] = (u - v) * (u - v);
+        }
+        pv.q[0] = e;
+    }
+}
+
+// A range-checked window on `bytes` bytes at `p` (uniform inputs): stores through it at an offset beyond `bytes` are
+// dropped by the hardware, which is how the row loops below switch a store off WITHOUT a branch around it -- behind a
+// branch the compiler cannot count the store among the operations in flight and waits, at every later use of a
+// prefetched row, until all older stores have been acknowledged (vmcnt counts loads and stores in issue order).
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t ws_window(const void* p, size_t bytes)
+{
+    const uintptr_t b = reinterpret_cast<uintptr_t>(p);
+    const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(b & 0xffffffffu));
+    const unsigned hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(b >> 32));
+    const unsigned n = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)bytes);
+    return __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void*>((uintptr_t)lo | ((uintptr_t)hi << 32)), (short)0, (int)n, 0x00020000);
+}
+constexpr unsigned WS_DROP = 0x80000000u;      // a byte offset no window reaches (planes stay below 2 GiB: Geom)
+
+// The weights of a lane's row in two steps, a row apart.  ws_lookup_issue: the head of the table from LDS for all eight
+// indices, and for every index beyond the head ONE gather from the full table in memory (768 KB, L2-resident) -- issued
+// unconditionally through a range-checked window, at an offset no window reaches when the index lies inside the head,
+// so lanes that need nothing fetch nothing and no branch surrounds a memory operation.  ws_lookup_finish, a row later:
+// a fetched weight is never +0 (the table holds -exp(..): at worst -0), a dropped fetch returns +0 -- that bit pattern
+// is the selector.  Round 3: the table indices of NATURAL images exceed the head in 1.5-4 % of the pixels
+// (tools/real_guide_time.py); the version before this one fetched those one lane at a time with dependent scalar loads
+// inside a branch and took 3.5x as long on the KITTI fixture as on the benchmark's synthetic scene.
+struct WsPending { float wl[2 * WS_COLS]; unsigned g[2 * WS_COLS]; };
+__device__ __forceinline__ void ws_lookup_issue(const float* lut_head, const __amdgpu_buffer_rsrc_t& lutwin, const int (&hidx)[WS_COLS],
+                                                const int (&vidx)[WS_COLS], WsPending& p)
+{
+#pragma unroll
+    for (int k = 0; k < WS_COLS; k++) {
+        p.wl[k] = lut_head[min(hidx[k], WS_LUT_HEAD - 1)];
+        p.wl[WS_COLS + k] = lut_head[min(vidx[k], WS_LUT_HEAD - 1)];
+    }
+#pragma unroll
+    for (int k = 0; k < WS_COLS; k++) {
+        p.g[k] = __builtin_amdgcn_raw_buffer_load_b32(lutwin, hidx[k] >= WS_LUT_HEAD ? (unsigned)hidx[k] * 4u : WS_DROP, 0, 0);
+        p.g[WS_COLS + k] = __builtin_amdgcn_raw_buffer_load_b32(lutwin, vidx[k] >= WS_LUT_HEAD ? (unsigned)vidx[k] * 4u : WS_DROP, 0, 0);
+    }
+}
+__device__ __forceinline__ void ws_lookup_finish(const WsPending& p, float (&wh)[WS_COLS], float (&wv)[WS_COLS])
+{
+#pragma unroll
+    for (int k = 0; k < WS_COLS; k++) {
+        wh[k] = p.g[k] != 0u ? __uint_as_float(p.g[k]) : p.wl[k];
+        wv[k] = p.g[WS_COLS + k] != 0u ? __uint_as_float(p.g[WS_COLS + k]) : p.wl[WS_COLS + k];
+    }
+}
+
+// Store side of a lane: Chor row-major [rh][pw], Cvert strip-major [pw/16][rh][16] or row-major; Chor is 0 in the ROI's
+// last column (FGS.cpp:614), Cvert in its last row (FGS.cpp:658-660), and both planes stay 0 on pitch padding.
+struct WsOut {
+    __amdgpu_buffer_rsrc_t chor, cvert; unsigned mh[WS_COLS], mv[WS_COLS]; unsigned ho, vo, hstep, vstep; bool st_ok, strip;
+    __device__ __forceinline__ void init(const WeightArgs& a, size_t pz, int j0, int y_first)
+    {
+        const Geom& g = a.g;
+        chor = ws_window(a.chor + pz * g.plane, g.plane * sizeof(float));
+        cvert = ws_window(a.cvert + pz * g.plane, g.plane * sizeof(float));
+        strip = a.cvert_orient == ORIENT_STRIP;
+#pragma unroll
+        for (int k = 0; k < WS_COLS; k++) { mh[k] = (j0 + k < g.rw - 1) ? 0xffffffffu : 0u; mv[k] = (j0 + k < g.rw) ? 0xffffffffu : 0u; }
+        st_ok = j0 >= 0 && j0 < g.pw;
+        ho = ((unsigned)y_first * (unsigned)g.pw + (unsigned)j0) * 4u;                             // byte offset of Chor(y_first, j0)
+        vo = (strip ? ((unsigned)(j0 >> 4) * (unsigned)g.rh + (unsigned)y_first) * ADF_STRIP + (unsigned)(j0 & 15)
+                    : (unsigned)y_first * (unsigned)g.pw + (unsigned)j0) * 4u;                     // ... of Cvert(y_first, j0)
+        hstep = (unsigned)g.pw * 4u; vstep = (strip ? (unsigned)ADF_STRIP : (unsigned)g.pw) * 4u;
+    }
+    // Chor of ROI row y_first + t (`on`: uniform -- this step has such a row)
+    __device__ __forceinline__ void store_h(int t, const float (&wh)[WS_COLS], bool on) const
+    {
+        ws_v4u o;
+#pragma unroll
+        for (int k = 0; k < WS_COLS; k++) o[k] = __float_as_uint(wh[k]) & mh[k];
+#ifdef ADF_WS_TEST_NOSTORE   // timing experiment only (wrong results): the values are formed, nothing is stored
+        asm volatile("" :: "v"(o));
+        return;
+#endif
+        __builtin_amdgcn_raw_buffer_store_b128(o, chor, (on && st_ok) ? ho + (unsigned)t * hstep : WS_DROP, 0, 2 /* nt: read much later */);
+    }
+    // Cvert of ROI row y_first + t (zero when that is the ROI's last row)
+    __device__ __forceinline__ void store_v(int t, const float (&wv)[WS_COLS], bool last_row, bool on) const
+    {
+        const unsigned last = last_row ? 0u : 0xffffffffu;
+        ws_v4u o;
+#pragma unroll
+        for (int k = 0; k < WS_COLS; k++) o[k] = __float_as_uint(wv[k]) & mv[k] & last;
+#ifdef ADF_WS_TEST_NOSTORE
+        asm volatile("" :: "v"(o));
+        return;
+#endif
+        // strip-major: four lanes write one 64-byte piece of the strip's stream per row and the following rows
+        // complete the line, so plain stores (L2 merges them); row-major: streaming stores
+        const unsigned off = (on && st_ok) ? vo + (unsigned)t * vstep : WS_DROP;
+        if (strip) __builtin_amdgcn_raw_buffer_store_b128(o, cvert, off, 0, 0);
+        else __builtin_amdgcn_raw_buffer_store_b128(o, cvert, off, 0, 2);
+    }
+};
 
 // Block (bx, by) of nby row blocks, image pz.  `active`: the thread is one of the WS_NT that do the work -- a launch
 // with wider blocks (the merged preparation kernel below conf_band_kernel) parks its other waves here: they take part
@@ -59,12 +225,11 @@ template <int CH>
 __device__ __forceinline__ void weights_stream_body(const WeightArgs& a, int bx, int by, int nby, size_t pz, WsShared<CH>& sh, bool active)
 {
     static_assert(CH == 1 || CH == 3, "guides have one or three channels");
-    constexpr int LUT_HEAD = WS_LUT_HEAD;
-    float (&lut_head)[LUT_HEAD] = sh.lut_head;
+    float (&lut_head)[WS_LUT_HEAD] = sh.lut_head;
     const Geom& g = a.g;
     const int tid = active ? (int)threadIdx.x : 0;
     if (active)
-        for (int q = tid; q < LUT_HEAD; q += WS_NT) lut_head[q] = a.lut[q];
+        for (int q = tid; q < WS_LUT_HEAD; q += WS_NT) lut_head[q] = a.lut[q];
     __syncthreads();
     const int ws_rows = (g.rh + nby - 1) / nby;
     const int x0 = bx * WS_BCOLS, y0 = by * ws_rows;
@@ -74,73 +239,36 @@ __device__ __forceinline__ void weights_stream_body(const WeightArgs& a, int bx,
 #endif
     const int nrows = min(ws_rows, g.rh - y0) + 1;             // one extra row feeds the last vertical difference
     const int j0 = x0 + WS_COLS * tid;                         // first ROI column of this lane
-    float* chor = a.chor + pz * g.plane;
-    float* cvert = a.cvert + pz * g.plane;
-    const bool strip = a.cvert_orient == ORIENT_STRIP;
 
-    // buffer descriptor over image rows r_first .. r_last of this pair, base aligned down to a dword; everything it is
-    // built from is uniform (kernel arguments and block indices) and said to be so
+    // image rows r_first .. r_last of this pair behind one descriptor
     const int r_first = g.ry + y0, r_last = g.ry + min(y0 + nrows - 1, g.rh - 1);
-    const uintptr_t base0 = reinterpret_cast<uintptr_t>(a.guide) + (uintptr_t)((ptrdiff_t)pz * a.pair_stride + (ptrdiff_t)r_first * a.stride);
-    const unsigned mis = (unsigned)__builtin_amdgcn_readfirstlane((int)(base0 & 3u));
-    const unsigned blo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)((base0 - mis) & 0xffffffffu));
-    const unsigned bhi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)((base0 - mis) >> 32));
-    const unsigned stride = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)a.stride);
-    const unsigned records = (unsigned)__builtin_amdgcn_readfirstlane(
-        (int)((mis + (unsigned)(r_last - r_first) * stride + (unsigned)(g.W * CH) + 3u) & ~3u));
-    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
-        reinterpret_cast<void*>((uintptr_t)blo | ((uintptr_t)bhi << 32)), (short)0, (int)records, 0x00020000);
-    const unsigned col_off = mis + (unsigned)((g.rx + x0) * CH);   // bytes from the aligned base to the block's first pixel, row r_first
+    const WsGuide gd = ws_guide(reinterpret_cast<uintptr_t>(a.guide) + (uintptr_t)((ptrdiff_t)pz * a.pair_stride + (ptrdiff_t)r_first * a.stride),
+                                a.stride, r_last - r_first + 1, g.W * CH);
+    const unsigned col_off = gd.mis + (unsigned)((g.rx + x0) * CH);   // bytes from the aligned base to the block's first pixel, row r_first
     const unsigned lane_off = (unsigned)(tid * WS_COLS * CH);
+    // row n of the block = ROI row min(y0+n, rh-1): byte offset of the block's first pixel (its low two bits: the misalignment)
+    auto row_off = [&](int n) -> unsigned { return col_off + (unsigned)(min(y0 + n, g.rh - 1) - y0) * gd.stride; };
+    auto load = [&](int n) -> WsWin<CH> { return ws_load<CH>(gd, (row_off(n) & ~3u) + lane_off); };
 
-    // row n of the block = ROI row min(y0+n, rh-1): byte offset of the block's first pixel and its misalignment
-    auto row_off = [&](int n) -> unsigned { return col_off + (unsigned)(min(y0 + n, g.rh - 1) - y0) * stride; };
-    auto load = [&](int n) -> WsWin<CH> {
-        const unsigned wo = (row_off(n) & ~3u) + lane_off;
-        WsWin<CH> w;
-        if constexpr (CH == 3) {
-            w.a = __builtin_amdgcn_raw_buffer_load_b128(rsrc, wo, 0, 0);
-            w.b = __builtin_amdgcn_raw_buffer_load_b32(rsrc, wo + 16u, 0, 0);
-        } else {
-            w.a = __builtin_amdgcn_raw_buffer_load_b64(rsrc, wo, 0, 0);
-        }
-        return w;
-    };
-    // Head of the table from LDS.  The rare large index (a strong colour edge) is fetched with a SCALAR
-    // load, one needy lane at a time: a vector load here -- even one that almost never executes -- makes the
-    // compiler wait for vmcnt(0) before every store of the row loop, and on this target stores count in
-    // vmcnt too, so every row's stores would wait for the previous row's to be acknowledged.
-    auto lookup_big = [&](int idx, float w) -> float {
-        bool need = idx >= LUT_HEAD;
-        unsigned long long m = __ballot(need);
-        while (m) {                                            // wave-uniform
-            const int first = __ffsll((long long)m) - 1;
-            const int sidx = __builtin_amdgcn_readfirstlane(__shfl(idx, first));
-            // constant address space + uniform index = s_load_dword (lgkmcnt, not vmcnt); the table is
-            // written once by the host, long before this launch
-            const float ws = reinterpret_cast<const __attribute__((address_space(4))) float*>(reinterpret_cast<uintptr_t>(a.lut))[sidx];
-            if ((int)(threadIdx.x & 63) == first) { w = ws; need = false; }
-            m = __ballot(need);
-        }
-        return w;
-    };
-
-    // per-lane store masks: Chor is 0 in the ROI's last column (FGS.cpp:614) and both planes stay 0 on pitch padding
-    unsigned mh[WS_COLS], mv[WS_COLS];
+    WsOut out;
+    out.init(a, pz, j0, y0);
+    const __amdgpu_buffer_rsrc_t lutwin = ws_window(a.lut, sizeof(float) * ADF_LUT_LEVELS);
+    WsPrev<CH> pv;
 #pragma unroll
-    for (int k = 0; k < WS_COLS; k++) { mh[k] = (j0 + k < g.rw - 1) ? 0xffffffffu : 0u; mv[k] = (j0 + k < g.rw) ? 0xffffffffu : 0u; }
-    const bool st_ok = j0 < g.pw;
-    unsigned ho = (unsigned)y0 * (unsigned)g.pw + (unsigned)j0;                                    // float index of Chor(y0, j0)
-    unsigned vo = strip ? ((unsigned)(j0 >> 4) * (unsigned)g.rh + (unsigned)y0) * ADF_STRIP + (unsigned)(j0 & 15)
-                        : (unsigned)y0 * (unsigned)g.pw + (unsigned)j0;                            // ... of Cvert(y0, j0)
-    const unsigned vstep = strip ? (unsigned)ADF_STRIP : (unsigned)g.pw;
-
-    unsigned q[WS_COLS], qa[WS_COLS];                             // previous row: pixels / their a.a (CH == 1: q[0] holds the four bytes)
-#pragma unroll
-    for (int k = 0; k < WS_COLS; k++) { q[k] = 0; qa[k] = 0; }
+    for (int k = 0; k < WS_COLS; k++) { pv.q[k] = 0; pv.qa[k] = 0; }
     WsWin<CH> nxt[WS_U], cur[WS_U];
 #pragma unroll
     for (int s = 0; s < WS_U; s++) nxt[s] = load(s < nrows ? s : nrows - 1);
+    // Software pipeline, one row deep: row n+1's indices are formed and its look-ups issued BEFORE row n's weights are
+    // completed and stored, so a fetch from the full table has a row of work to arrive in.  Every step of a group runs,
+    // with no branch around a load or a store: steps past the block's last row work on a repeated row and their stores
+    // are switched off through the windows.
+    WsPending pend;
+    {
+        int hidx[WS_COLS], vidx[WS_COLS];
+        ws_indices<CH>(nxt[0], row_off(0) & 3u, pv, hidx, vidx);
+        ws_lookup_issue(lut_head, lutwin, hidx, vidx, pend);
+    }
     for (int n0 = 0; n0 < nrows; n0 += WS_U) {
 #pragma unroll
         for (int s = 0; s < WS_U; s++) {                        // the group's one wait happens here
@@ -152,70 +280,17 @@ __device__ __forceinline__ void weights_stream_body(const WeightArgs& a, int bx,
 #pragma unroll
         for (int s = 0; s < WS_U; s++) {
             const int n = n0 + s;
-            if (n < nrows) {                                   // block-uniform
-                const unsigned m = row_off(n) & 3u;            // (uniform) bytes the window starts before the first pixel
+            WsPending ahead;
+            {
                 int hidx[WS_COLS], vidx[WS_COLS];
-                if constexpr (CH == 3) {
-                    const unsigned e0 = __builtin_amdgcn_alignbyte(cur[s].a.y, cur[s].a.x, m), e1 = __builtin_amdgcn_alignbyte(cur[s].a.z, cur[s].a.y, m);
-                    const unsigned e2 = __builtin_amdgcn_alignbyte(cur[s].a.w, cur[s].a.z, m), e3 = __builtin_amdgcn_alignbyte(cur[s].b, cur[s].a.w, m);
-                    unsigned p[WS_COLS + 1], pa[WS_COLS + 1];  // pixels as [c0 c1 c2 0], and a.a
-                    p[0] = e0 & 0x00ffffffu;
-                    p[1] = __builtin_amdgcn_perm(e1, e0, 0x0c050403u);
-                    p[2] = __builtin_amdgcn_perm(e2, e1, 0x0c040302u);
-                    p[3] = e2 >> 8;
-                    p[4] = e3 & 0x00ffffffu;
-#pragma unroll
-                    for (int k = 0; k <= WS_COLS; k++) pa[k] = __builtin_amdgcn_udot4(p[k], p[k], 0u, false);
-#pragma unroll
-                    for (int k = 0; k < WS_COLS; k++) {
-                        hidx[k] = (int)(pa[k] + pa[k + 1]) - 2 * (int)__builtin_amdgcn_udot4(p[k], p[k + 1], 0u, false);
-                        vidx[k] = (int)(pa[k] + qa[k]) - 2 * (int)__builtin_amdgcn_udot4(p[k], q[k], 0u, false);
-                        q[k] = p[k]; qa[k] = pa[k];
-                    }
-                } else {
-                    const unsigned e = __builtin_amdgcn_alignbyte(cur[s].a.y, cur[s].a.x, m);
-                    const unsigned nb = __builtin_amdgcn_alignbyte(0u, cur[s].a.y, m) & 0xffu;
-#pragma unroll
-                    for (int k = 0; k < WS_COLS; k++) {
-                        const int v = (int)((e >> (8 * k)) & 0xffu);
-                        const int r = k < WS_COLS - 1 ? (int)((e >> (8 * k + 8)) & 0xffu) : (int)nb;
-                        const int u = (int)((q[0] >> (8 * k)) & 0xffu);
-                        hidx[k] = (v - r) * (v - r);
-                        vidx[k] = (u - v) * (u - v);
-                    }
-                    q[0] = e;
-                }
-                float wh[WS_COLS], wv[WS_COLS];
-                int big = 0;
-#pragma unroll
-                for (int k = 0; k < WS_COLS; k++) {
-                    wh[k] = lut_head[min(hidx[k], LUT_HEAD - 1)];
-                    wv[k] = lut_head[min(vidx[k], LUT_HEAD - 1)];
-                    big = max(big, max(hidx[k], vidx[k]));
-                }
-                if (__ballot(big >= LUT_HEAD)) {               // rare (wave-uniform): a strong edge somewhere in the wave's row
-#pragma unroll
-                    for (int k = 0; k < WS_COLS; k++) { wh[k] = lookup_big(hidx[k], wh[k]); wv[k] = lookup_big(vidx[k], wv[k]); }
-                }
-                const int i = y0 + n;                          // ROI row of this input row (when n < nrows-1)
-                if (n < nrows - 1 && st_ok) {                  // Chor of this row, FGS.cpp:607-614
-                    ws_v4f o;
-#pragma unroll
-                    for (int k = 0; k < WS_COLS; k++) o[k] = __uint_as_float(__float_as_uint(wh[k]) & mh[k]);
-                    ADF_PREP_ST(reinterpret_cast<ws_v4f*>(chor + ho), o);
-                }
-                if (n >= 1 && st_ok) {                         // Cvert of the previous row, FGS.cpp:635-660 (0 in the last row)
-                    const unsigned last = (i - 1 == g.rh - 1) ? 0u : 0xffffffffu;
-                    ws_v4f o;
-#pragma unroll
-                    for (int k = 0; k < WS_COLS; k++) o[k] = __uint_as_float(__float_as_uint(wv[k]) & mv[k] & last);
-                    // strip-major (ORIENT_STRIP): four lanes write one 64-byte piece of the strip's stream per row and the
-                    // following rows complete the line, so plain stores (L2 merges them); row-major: streaming stores
-                    if (strip) *reinterpret_cast<ws_v4f*>(cvert + (vo - vstep)) = o;
-                    else ADF_PREP_ST(reinterpret_cast<ws_v4f*>(cvert + (vo - vstep)), o);
-                }
-                ho += (unsigned)g.pw; vo += vstep;
+                ws_indices<CH>(s + 1 < WS_U ? cur[s + 1 < WS_U ? s + 1 : 0] : nxt[0], row_off(min(n + 1, nrows - 1)) & 3u, pv, hidx, vidx);
+                ws_lookup_issue(lut_head, lutwin, hidx, vidx, ahead);
             }
+            float wh[WS_COLS], wv[WS_COLS];
+            ws_lookup_finish(pend, wh, wv);
+            out.store_h(n, wh, n < nrows - 1);                                         // Chor of ROI row y0+n, FGS.cpp:607-614
+            out.store_v(n - 1, wv, y0 + n - 1 == g.rh - 1, n >= 1 && n < nrows);       // Cvert of the previous row, FGS.cpp:635-660
+            pend = ahead;
         }
     }
 }
