@@ -57,6 +57,8 @@ def parse_args(argv=None):
     ap.add_argument("--no-check", action="store_true", help="skip the oracle check of the first and last pair")
     ap.add_argument("--matcher-pairs", type=int, default=4,
                     help="pairs of the extra views -> matcher -> filter leg (SURVEY 8f N4; N=1 only, 0 = skip)")
+    ap.add_argument("--natural-pairs", type=int, default=8,
+                    help="pairs of the extra leg on a natural-image guide (0 = skip; N = 1 only)")
     ap.add_argument("--dry-run", action="store_true",
                     help="launcher / rendezvous rehearsal without a GPU: gloo, no filter call, value 0 (tests)")
     ap.add_argument("--roi", default="config",
@@ -526,11 +528,74 @@ def worker(args):
                 pipeline[m] = {"error": str(e)}
         line["views_to_filtered"] = pipeline
 
+    if rank == 0 and world == 1 and not dry and args.natural_pairs > 0:
+        try:
+            line["natural_guide"] = natural_guide_leg(adf, torch, dev, dl, dr, roi, radius, ch, min(args.natural_pairs, pairs),
+                                                      args.solver, not args.no_check)
+        except Exception as e:                               # the extra leg must never cost the bench line
+            line["natural_guide"] = {"error": str(e)}
+
     if watchdog is not None:
         watchdog.cancel()
     emit()
     if world > 1:
         dist.destroy_process_group()
+
+
+def natural_guide_leg(adf, torch, dev, dl, dr, roi, radius, ch, n, solver, check):
+    """The same filter call with a NATURAL-IMAGE guide: the reference's KITTI fixture (modules/stereo/testdata/imgKittyl.bmp,
+    a data fixture under tests/golden/) tiled to the config's frame, as `ch` channels (the gray value plus a little
+    per-channel noise).  `value` is quoted on MakeArtificialExample's scene, as the reference's perf test is
+    (perf_disparity_wls_filter.cpp:95-167); that scene's only strong colour edges are one rectangle's border, while
+    natural images send a few per cent of the edge-weight look-ups past the table head cached in LDS -- this leg shows
+    the rate there."""
+    import numpy as np
+    from PIL import Image
+
+    H, W = dl.shape[1], dl.shape[2]
+    im = np.array(Image.open(os.path.join(ROOT, "tests", "golden", "kitti_left.bmp")))
+    if im.ndim == 3:
+        im = im[:, :, 0]
+    tiled = np.ascontiguousarray(np.tile(im, ((H + im.shape[0] - 1) // im.shape[0], (W + im.shape[1] - 1) // im.shape[1]))[:H, :W])
+    g1 = torch.from_numpy(tiled).to(dev)[None].expand(n, H, W).contiguous()
+    if ch == 3:
+        gen = torch.Generator(device=dev)
+        gen.manual_seed(1)
+        guide = (g1[..., None].float() + 2.0 * torch.randn((n, H, W, 3), generator=gen, device=dev)).round_().clamp_(0, 255).to(torch.uint8)
+        dh = ((guide[0, :, 1:].int() - guide[0, :, :-1].int()) ** 2).sum(-1)
+    else:
+        guide = g1
+        dh = (guide[0, :, 1:].int() - guide[0, :, :-1].int()) ** 2
+    beyond = float((dh >= 2048).float().mean().item())
+    f = adf.createDisparityWLSFilterGeneric(True)
+    f.setLambda(8000.0); f.setSigmaColor(1.5); f.setDepthDiscontinuityRadius(radius)
+    f.setSolver(adf.SOLVER_WAVE if solver == "wave" else adf.SOLVER_EXACT)
+    dln, drn = dl[:n].contiguous(), dr[:n].contiguous()
+    out = None
+    for _ in range(2):
+        out = f.filter(dln, guide, out, drn, roi)
+    torch.cuda.synchronize()
+    steps = 5
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(steps):
+        f.filter(dln, guide, out, drn, roi)
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / steps
+    res = {"guide": "tests/golden/kitti_left.bmp tiled to %dx%d, %d channel(s)" % (W, H, ch), "pairs": n,
+           "table_indices_beyond_lds_head": round(beyond, 4), "ms_per_step": round(ms, 3),
+           "Mpixels_per_s": round(n * W * H / ms / 1e3, 1),
+           "note": "same call as `value` on a natural-image guide; not part of `value`"}
+    if check:
+        import oracle
+        p = oracle.default_params(threads=min(32, os.cpu_count() or 1), sigma_color=1.5, disc_radius=radius)
+        exp, exp_conf = oracle.wls_filter(dln[0].cpu().numpy(), guide[0].cpu().numpy(), drn[0].cpu().numpy(), roi, p)
+        got = out[0].cpu().numpy()
+        d = np.abs(got.astype(np.int32) - exp.astype(np.int32))
+        res["checked"] = {"pair": 0, "confidence_bit_exact": bool(np.array_equal(f.getConfidenceMap(0).cpu().numpy(), exp_conf)),
+                          "disparity_max_abs_lsb": int(d.max()), "disparity_mean_abs_lsb": float(d.mean())}
+    return res
 
 
 def device_identity(torch, dev, dry, rank, local_rank):
@@ -708,6 +773,7 @@ def build_line(args, dry, world, backend, n_total, pairs, W, H, ch, roi, roi_kin
         "rccl_legs": None,
         "workspace_GB": workspace_gb,
         "views_to_filtered": None,
+        "natural_guide": None,
     }
     if dry:
         line["dry_run"] = True

@@ -40,3 +40,7 @@ def test_bench_line_contract():
     v = d["views_to_filtered"]["bm"]                 # extra leg: device matcher feeding the filter
     assert "error" not in v, v
     assert v["matcher_ms_per_pair"] > 0 and v["filter_ms_per_pair"] > 0 and v["num_disparities"] % 16 == 0
+    ng = d["natural_guide"]                          # extra leg: the same call on a natural-image guide (round 3)
+    assert "error" not in ng, ng
+    assert ng["Mpixels_per_s"] > 0 and 0 < ng["table_indices_beyond_lds_head"] < 0.2
+    assert ng["checked"]["confidence_bit_exact"] is True and ng["checked"]["disparity_max_abs_lsb"] <= 1
