@@ -11,6 +11,7 @@
 // for the exact solver, whose horizontal sweep wants the row index fastest.
 #include "adf_internal.h"
 #include "prep_bodies.h"
+#include <cstdlib>
 
 namespace adf {
 
@@ -172,7 +173,8 @@ hipError_t launch_weights(const WeightArgs& a, int n_pairs, hipStream_t st)
     if (a.cvert_orient != ORIENT_N && !(a.cvert_orient == ORIENT_STRIP && a.chor_orient == ORIENT_N)) return hipErrorInvalidValue;
     // row-major Chor: the streaming kernel -- unless a block's slice of the guide cannot be put behind one 32-bit buffer
     // descriptor (row strides of a gigabyte: the generic tile kernel below takes those)
-    if (a.chor_orient == ORIENT_N && a.stride > 0 && a.stride < ((ptrdiff_t)1 << 29) && (size_t)a.g.W * a.ch < ((size_t)1 << 29)) {
+    static const bool force_generic = [] { const char* e = getenv("ADF_WEIGHTS_GENERIC"); return e && atoi(e) != 0; }();   // test hook
+    if (!force_generic && a.chor_orient == ORIENT_N && a.stride > 0 && a.stride < ((ptrdiff_t)1 << 29) && (size_t)a.g.W * a.ch < ((size_t)1 << 29)) {
         dim3 sgrid((a.g.rw + prep::WS_BCOLS - 1) / prep::WS_BCOLS, 1, n_pairs);
         {
             // rows per block: tall blocks amortise the table load and the extra row; enough blocks for the chip; and few

@@ -84,3 +84,34 @@ def test_generic_fgs_weights_bit_exact_with_strong_edges(adf, oracle):
     f = adf.createFastGlobalSmootherFilter(guide, 300.0, 12.0, solver=adf.SOLVER_EXACT)
     got = f.filter(src)
     assert np.array_equal(np.asarray(got), exp)
+
+
+def test_generic_tile_kernel_takes_over_for_huge_strides(adf, oracle):
+    """Guides whose row stride does not fit the streaming kernel's 32-bit buffer descriptors go through the generic tile
+    kernel, which then has to write the wave solver's strip-major Cvert itself; ADF_WEIGHTS_GENERIC=1 forces that path
+    (a gigabyte stride cannot be allocated in a test).  A child process, because the switch is read once per process."""
+    import os
+    import subprocess
+    import sys
+
+    code = r'''
+import numpy as np, sys, os
+sys.path.insert(0, os.getcwd())
+import addingdisparityfiltering_amd as adf, oracle
+from addingdisparityfiltering_amd import synthetic
+view, dl, dr, roi = synthetic.make_artificial_example(333, 97, 3, seed=4)
+p = oracle.default_params(threads=4, sigma_color=2.5, disc_radius=3)
+exp, exp_conf = oracle.wls_filter(dl, view, dr, roi, p)
+for solver, tol in ((adf.SOLVER_EXACT, 0), (adf.SOLVER_WAVE, 1)):
+    f = adf.createDisparityWLSFilterGeneric(True)
+    f.setSolver(solver); f.setSigmaColor(2.5); f.setDepthDiscontinuityRadius(3)
+    got = f.filter(dl, view, None, dr, roi)
+    d = int(np.abs(got.astype(np.int32) - exp.astype(np.int32)).max())
+    assert d <= tol, (solver, d)
+    assert np.array_equal(f.getConfidenceMap(), exp_conf)
+print("ok")
+'''
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, ADF_WEIGHTS_GENERIC="1", ADF_MERGE_SMALL="0")
+    r = subprocess.run([sys.executable, "-c", code], cwd=root, env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "ok" in r.stdout, r.stderr[-2000:]
