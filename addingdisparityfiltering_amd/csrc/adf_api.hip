@@ -112,25 +112,41 @@ struct DevBuf {
     void release() { if (p) hipFree(p); p = nullptr; bytes = 0; }
 };
 
-// Weight LUT (FGS.cpp:150-154, 663-675), built on the host with libm and cached per sigma.
+// Weight LUTs (FGS.cpp:150-154, 663-675), built on the host with libm, one immutable device table per sigma seen
+// (up to LUT_CACHE of them).  Round 3: a table is never rewritten, so coming back to a sigma used before -- the common
+// way callers vary it -- is a pointer switch with no device work and no synchronisation (capturable into a hipGraph),
+// and a NEW sigma no longer drains the stream: its table goes into a fresh buffer no kernel in flight can be reading.
+// Only that first upload is a synchronous copy (the pageable staging vector dies at scope exit); a caller that captures
+// filter calls must have used every sigma it switches between once before the capture (include/adf_wls.h).
 struct Lut {
-    DevBuf dev; float sigma = -1.0f; bool valid = false;
+    static constexpr int LUT_CACHE = 8;
+    struct Entry { float sigma; float* dev; unsigned long long used; };
+    std::vector<Entry> tables;
+    const float* cur = nullptr;
+    unsigned long long tick = 0;
+    size_t bytes() const { return tables.size() * sizeof(float) * ADF_LUT_LEVELS; }
     int ensure(float s, hipStream_t st)
     {
-        if (valid && s == sigma) return ADF_OK;
+        for (auto& e : tables)
+            if (e.sigma == s) { e.used = ++tick; cur = e.dev; return ADF_OK; }
+        if ((int)tables.size() >= LUT_CACHE) {                 // evict the least recently used table: kernels of
+            size_t lru = 0;                                    // earlier calls on `st` may still read it
+            for (size_t k = 1; k < tables.size(); k++) if (tables[k].used < tables[lru].used) lru = k;
+            HIP_TRY(hipStreamSynchronize(st));
+            HIP_TRY(hipFree(tables[lru].dev));
+            tables.erase(tables.begin() + (ptrdiff_t)lru);
+        }
         std::vector<float> host(ADF_LUT_LEVELS);
         for (int i = 0; i < ADF_LUT_LEVELS; i++) host[i] = -expf(-sqrtf((float)i) / s);
-        int rc = dev.reserve(sizeof(float) * ADF_LUT_LEVELS, st);
-        if (rc) return rc;
-        // A change of sigma re-builds the table: kernels of earlier calls on `st` may still read the old one, so the
-        // stream is drained first, and the copy is synchronous because the pageable staging vector dies at scope exit.
-        // Both are host synchronisations: a caller that captures filter calls into a hipGraph must set sigma (and run
-        // one call) BEFORE the capture -- a sigma change between captured calls cannot be captured (include/adf_wls.h).
-        HIP_TRY(hipStreamSynchronize(st));
-        HIP_TRY(hipMemcpy(dev.p, host.data(), sizeof(float) * ADF_LUT_LEVELS, hipMemcpyHostToDevice));
-        sigma = s; valid = true;
+        float* d = nullptr;
+        HIP_TRY(hipMalloc(&d, sizeof(float) * ADF_LUT_LEVELS));
+        hipError_t e = hipMemcpy(d, host.data(), sizeof(float) * ADF_LUT_LEVELS, hipMemcpyHostToDevice);
+        if (e != hipSuccess) { hipFree(d); return fail(ADF_EHIP, "LUT upload failed: %s", hipGetErrorString(e)); }
+        tables.push_back(Entry{s, d, ++tick});
+        cur = d;
         return ADF_OK;
     }
+    void release() { for (auto& e : tables) hipFree(e.dev); tables.clear(); cur = nullptr; }
 };
 
 // Per-launch HIP-event timing (adf_wls_profile_*).  Events are pooled and reused.
@@ -351,7 +367,7 @@ extern "C" void adf_wls_destroy(adf_wls_t* h)
 {
     if (!h) return;
     DeviceScope ds(h->device);
-    h->lut.dev.release(); h->ws.release(); h->conf.release(); h->stage.release(); h->scaled.release();
+    h->lut.release(); h->ws.release(); h->conf.release(); h->stage.release(); h->scaled.release();
     h->prof.destroy();
     if (h->ev_fork) hipEventDestroy(h->ev_fork);
     if (h->ev_join) hipEventDestroy(h->ev_join);
@@ -393,7 +409,7 @@ extern "C" int adf_wls_get_device(const adf_wls_t* h, int* device) { NEED_HANDLE
 extern "C" int adf_wls_get_roi(const adf_wls_t* h, adf_rect* roi) { NEED_HANDLE(h); if (roi) *roi = h->roi; return ADF_OK; }
 extern "C" size_t adf_wls_workspace_bytes(const adf_wls_t* h)
 {
-    return h ? h->ws.bytes + h->conf.bytes + h->stage.bytes + h->scaled.bytes + h->lut.dev.bytes : 0;
+    return h ? h->ws.bytes + h->conf.bytes + h->stage.bytes + h->scaled.bytes + h->lut.bytes() : 0;
 }
 
 extern "C" int adf_wls_sync(adf_wls_t* h, void* stream)
@@ -531,7 +547,7 @@ static int wls_filter_impl(adf_wls_t* h, int n_pairs,
             ProfScope ps(prof, K_FILL, 2.0 * (F - P), 2.0 * (F - P), st);
             HIP_TRY(launch_outside(oa, n, st));
         }
-        WeightArgs wa{gv, sG, psG, gch, (const float*)h->lut.dev.p, p.CH, p.CV, orient_h, orient_cv, g,
+        WeightArgs wa{gv, sG, psG, gch, h->lut.cur, p.CH, p.CV, orient_h, orient_cv, g,
                       wave ? nullptr : p.B0};   // exact: B0 is free until the first pass writes its output there
         // confidence mode: the weights depend on the guide only and the confidence kernels on the disparity
         // maps only -- one is bound by memory latency, the others lean on the vector ALUs -- so the weight
@@ -919,7 +935,7 @@ static int fgs_create_impl(adf_fgs_t** out, const uint8_t* guide, ptrdiff_t gstr
         : hipMemcpy2D(f->io.p, (size_t)w * gch, guide, gstride, (size_t)w * gch, hgt, hipMemcpyHostToDevice);
     if (e == hipSuccess) {
         float* base = (float*)f->planes.p;
-        WeightArgs wa{(const uint8_t*)f->io.p, (ptrdiff_t)w * gch, 0, gch, (const float*)f->lut.dev.p,
+        WeightArgs wa{(const uint8_t*)f->io.p, (ptrdiff_t)w * gch, 0, gch, f->lut.cur,
                       base, base + f->g.plane, f->solver == ADF_SOLVER_WAVE ? ORIENT_N : ORIENT_T,
                       f->solver == ADF_SOLVER_WAVE ? ORIENT_STRIP : ORIENT_N, f->g,
                       f->solver == ADF_SOLVER_WAVE ? nullptr : base + 5 * f->g.plane};   // B0
@@ -957,7 +973,7 @@ extern "C" void adf_fgs_destroy(adf_fgs_t* f)
 {
     if (!f) return;
     DeviceScope ds(f->device);
-    f->lut.dev.release(); f->planes.release(); f->io.release();
+    f->lut.release(); f->planes.release(); f->io.release();
     if (f->weights_done) hipEventDestroy(f->weights_done);
     delete f;
 }

@@ -94,8 +94,9 @@ void adf_wls_destroy(adf_wls_t* h);
 /* DisparityWLSFilter get/set (DF.hpp:90-122, DF.cpp:126-136). */
 int adf_wls_set_lambda(adf_wls_t* h, double lambda);
 int adf_wls_get_lambda(const adf_wls_t* h, double* lambda);
-/* (a new sigma_color re-builds the weight table inside the next filter call, which synchronises the stream once:
- * set it, and run one call, BEFORE capturing filter calls into a hipGraph) */
+/* (every sigma_color a handle has seen keeps its own immutable weight table on the device, up to eight: coming back to
+ * one is free and capturable; a NEW value builds its table on the host inside the next filter call and uploads it with
+ * one synchronous copy -- use each sigma once BEFORE capturing filter calls that switch between them into a hipGraph) */
 int adf_wls_set_sigma_color(adf_wls_t* h, double sigma_color);
 int adf_wls_get_sigma_color(const adf_wls_t* h, double* sigma_color);
 int adf_wls_set_lrc_thresh(adf_wls_t* h, int lrc_thresh);

@@ -244,6 +244,38 @@ def test_filter_call_is_graph_capturable(adf, oracle):
     assert not torch.equal(out, eager)
 
 
+def test_switching_between_known_sigmas_is_graph_capturable(adf, oracle):
+    """Every sigma a handle has seen keeps its own immutable table (round 3): captured calls may switch between them --
+    no synchronisation, no upload -- and a replay uses the table of the sigma that was set when the call was captured."""
+    import torch
+
+    view, dl, dr, roi, radius = synthetic.make_config_example(1)
+    dev = torch.device("cuda:0")
+    tv, tl, tr = (torch.from_numpy(a).to(dev) for a in (view, dl, dr))
+    outs = [torch.empty(dl.shape, dtype=torch.int16, device=dev) for _ in range(2)]
+    f = adf.createDisparityWLSFilterGeneric(True)
+    f.setSolver(adf.SOLVER_WAVE); f.setDepthDiscontinuityRadius(radius)
+    for sig in (1.5, 7.0):                                          # both tables exist before the capture
+        f.setSigmaColor(sig); f.filter(tl, tv, outs[0], tr, roi)
+    torch.cuda.synchronize()
+    s = torch.cuda.Stream()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.stream(s):
+        s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.graph(g, stream=s):
+            f.setSigmaColor(1.5); f.filter(tl, tv, outs[0], tr, roi)
+            f.setSigmaColor(7.0); f.filter(tl, tv, outs[1], tr, roi)
+    for o in outs:
+        o.zero_()
+    g.replay()
+    torch.cuda.synchronize()
+    for sig, o in zip((1.5, 7.0), outs):
+        exp, _ = oracle.wls_filter(dl, view, dr, roi, oracle.default_params(sigma_color=sig, disc_radius=radius, threads=8))
+        d = np.abs(o.cpu().numpy().astype(np.int64) - exp)
+        assert d.max() <= MAX_DIF and d.mean() <= MAX_MEAN_DIF, sig
+    assert not torch.equal(outs[0], outs[1])
+
+
 def test_device_call_is_graph_capturable(adf):
     """once the workspace exists the device entry point queues kernels only (the side
     stream's fork / join included), so a call can be captured into a HIP graph and replayed."""
