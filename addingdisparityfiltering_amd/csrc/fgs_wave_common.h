@@ -419,5 +419,38 @@ __device__ __forceinline__ void pcr64(int lane, float al, float be, float ga, fl
 }
 
 
+// A 128-row reduced system (scanlines longer than 64 chunks: two waves per row / 128 chunks per column, round 3), solved
+// by ONE wavefront from LDS: lane l takes rows 2l-1, 2l, 2l+1, eliminates the odd neighbours from the even row (one
+// step of cyclic reduction), the 64 even rows go through the wave-wide PCR above, and the odd rows follow by
+// substitution.  Rows are read as row[k * stride]; solutions are written the same way.  The caller puts a workgroup
+// barrier before (rows complete) and after (solutions visible).
+template <int R>
+__device__ __forceinline__ void reduced128(int lane, const float* al, const float* be, const float* ga, const float* p0, const float* p1,
+                                           int stride, float* x0, float* x1)
+{
+    const int e = 2 * lane, o = e + 1, m = lane > 0 ? e - 1 : 0;
+    const float al_e = al[e * stride], be_e = be[e * stride], ga_e = ga[e * stride], p0_e = p0[e * stride];
+    const float al_o = al[o * stride], be_o = be[o * stride], ga_o = ga[o * stride], p0_o = p0[o * stride];
+    const float al_m = al[m * stride], be_m = be[m * stride], ga_m = ga[m * stride], p0_m = p0[m * stride];
+    const float p1_e = (R > 1) ? p1[e * stride] : 0.0f, p1_o = (R > 1) ? p1[o * stride] : 0.0f, p1_m = (R > 1) ? p1[m * stride] : 0.0f;
+    const float k1 = lane > 0 ? qdiv<4>(al_e, be_m, rcp_nr(be_m)) : 0.0f;     // (row 0 has no predecessor: its alpha is 0)
+    const float k2 = qdiv<4>(ga_e, be_o, rcp_nr(be_o));
+    const float AL = -al_m * k1, GA = -ga_o * k2;
+    const float BE = __builtin_fmaf(-al_o, k2, __builtin_fmaf(-ga_m, k1, be_e));
+    const float P0 = __builtin_fmaf(-p0_o, k2, __builtin_fmaf(-p0_m, k1, p0_e));
+    const float P1 = (R > 1) ? __builtin_fmaf(-p1_o, k2, __builtin_fmaf(-p1_m, k1, p1_e)) : 0.0f;
+    float xe0, xe1;
+    pcr64<R>(lane, AL, BE, GA, P0, P1, xe0, xe1);
+    const float xn0 = __shfl_down(xe0, 1), xn1 = (R > 1) ? __shfl_down(xe1, 1) : 0.0f;   // (lane 63: row 127's gamma is 0)
+    const float rb = rcp_nr(be_o);
+    const float xo0 = qdiv<4>(__builtin_fmaf(-ga_o, xn0, __builtin_fmaf(-al_o, xe0, p0_o)), be_o, rb);
+    x0[e * stride] = xe0; x0[o * stride] = xo0;
+    if (R > 1) {
+        const float xo1 = qdiv<4>(__builtin_fmaf(-ga_o, xn1, __builtin_fmaf(-al_o, xe1, p1_o)), be_o, rb);
+        x1[e * stride] = xe1; x1[o * stride] = xo1;
+    }
+}
+
+
 } // namespace wave
 } // namespace adf

@@ -18,12 +18,23 @@ using namespace wave;
 // of being read from planes a prologue kernel would have had to write.
 // (the longest chunk with two right-hand sides does not fit two waves per SIMD without spilling: the
 // pair staging below keeps both right-hand sides and two of the three load batches alive at once)
-template <int M, int R, bool FUSED>
-__global__ void __launch_bounds__(64, (M > ADF_H_TWO_WAVE_MAX && R > 1) ? 1 : 2) wave_hpass_kernel(WavePassArgs a)
+// NW = 2 (round 3): rows longer than 64 chunks of 64 elements (ROIs wider than 4096 columns: 8K frames) are solved by TWO
+// wavefronts of one workgroup, wave w owning columns [w*64*M, (w+1)*64*M) -- its own staging buffer, its own loads and
+// stores, the chunk sweeps unchanged -- and meeting the other three times through LDS: the weight in front of chunk 64,
+// the left-end coefficients of chunk 64 for chunk 63's separator row, and the 128-row reduced system, which wave 0
+// solves (fgs_wave_common.h, reduced128).
+template <int M, int R, bool FUSED, int NW = 1>
+__global__ void __launch_bounds__(64 * NW, (M > (NW == 2 ? 40 : ADF_H_TWO_WAVE_MAX) && R > 1) ? 1 : 2) wave_hpass_kernel(WavePassArgs a)
 {
     static_assert(M % 4 == 0 && M >= 4, "chunk length must be a multiple of 4");
-    __shared__ float4 stage[M * 16];
-    const int lane = threadIdx.x;
+    static_assert(NW == 1 || NW == 2, "one or two wavefronts per row");
+    __shared__ float4 stage_all[NW][M * 16];
+    __shared__ float xch[NW == 2 ? 5 : 1];              // c in front of chunk 64; GS0, GS1, PS, QS of chunk 64
+    __shared__ float red[NW == 2 ? 5 : 1][NW == 2 ? 128 : 1];   // separator rows
+    __shared__ float xsol[NW == 2 ? 2 : 1][NW == 2 ? 128 : 1];  // their solutions
+    const int lane = threadIdx.x & 63, wv = NW == 2 ? (int)(threadIdx.x >> 6) : 0;
+    float4* stage = stage_all[wv];
+    const int v0 = wv * 16 * M;                          // first float4 of this wave's columns in a row-major row
     const size_t off = (size_t)blockIdx.y * a.plane + (size_t)blockIdx.x * a.pitch;
     const int nvec = a.pitch >> 2;
     // R == 2: the two right-hand sides live in one pair plane, interleaved per 16 columns
@@ -66,9 +77,11 @@ __global__ void __launch_bounds__(64, (M > ADF_H_TWO_WAVE_MAX && R > 1) ? 1 : 2)
         short4 draw[FUSED ? M / 4 : 1];                          // fused: the row of the left disparity map
         // (an explicit branch per load: "cond ? *p : zero" would make the compiler select between
         // addresses and park the zero in scratch memory)
+        // (idx: float4 of the row-major row; uidx: float4 of this wave's part of the interleaved pair row, 2 * M * 64 floats)
+        const int u0 = PAIR ? 2 * v0 : v0;
 #pragma unroll
         for (int k = 0; k < M / 4; k++) {
-            const int idx = 64 * k + lane;
+            const int idx = v0 + 64 * k + lane, uidx = u0 + 64 * k + lane;
             tC[k] = make_float4(0.f, 0.f, 0.f, 0.f); t0[k] = tC[k]; t1[k] = tC[k];
             if (FUSED) draw[k] = make_short4(0, 0, 0, 0);
             if (FUSED) {
@@ -87,15 +100,16 @@ __global__ void __launch_bounds__(64, (M > ADF_H_TWO_WAVE_MAX && R > 1) ? 1 : 2)
                 // non-temporal: every byte of a row pass is used exactly once (measured -5 % on the pass)
                 typedef float v4f __attribute__((ext_vector_type(4)));
                 if (idx < nvec) { const v4f q = __builtin_nontemporal_load(reinterpret_cast<const v4f*>(sC) + idx); tC[k] = make_float4(q.x, q.y, q.z, q.w); }
-                if (idx < nvecU) { const v4f q = __builtin_nontemporal_load(reinterpret_cast<const v4f*>(s0) + ADF_PIDX(idx)); t0[k] = make_float4(q.x, q.y, q.z, q.w); }
-                if (PAIR && idx + 64 * MQ < nvecU) { const v4f q = __builtin_nontemporal_load(reinterpret_cast<const v4f*>(s0) + ADF_PIDX(idx + 64 * MQ)); t1[k] = make_float4(q.x, q.y, q.z, q.w); }
+                if (uidx < nvecU) { const v4f q = __builtin_nontemporal_load(reinterpret_cast<const v4f*>(s0) + ADF_PIDX(uidx)); t0[k] = make_float4(q.x, q.y, q.z, q.w); }
+                if (PAIR && uidx + 64 * MQ < nvecU) { const v4f q = __builtin_nontemporal_load(reinterpret_cast<const v4f*>(s0) + ADF_PIDX(uidx + 64 * MQ)); t1[k] = make_float4(q.x, q.y, q.z, q.w); }
             }
         }
         if (FUSED) {                                             // U1 = conf, U0 = conf * float(dL)  (DF.cpp:288-290)
-            const int ktail = rem ? (nfull >> 6) : -1;           // wave-uniform: the one k that holds the partial vector
+            const int tl = nfull - v0;                           // the partial vector, counted from this wave's first
+            const int ktail = (rem && tl >= 0 && tl < 16 * M) ? (tl >> 6) : -1;   // wave-uniform: the one k that holds it
 #pragma unroll
             for (int k = 0; k < M / 4; k++) {
-                if (k == ktail && lane == (nfull & 63)) {        // elements rem..3 lie past the row
+                if (k == ktail && lane == (tl & 63)) {           // elements rem..3 lie past the row
                     const int sh = 16 * (4 - rem);
                     unsigned long long w = (unsigned long long)(unsigned short)draw[k].x | ((unsigned long long)(unsigned short)draw[k].y << 16) |
                                            ((unsigned long long)(unsigned short)draw[k].z << 32) | ((unsigned long long)(unsigned short)draw[k].w << 48);
@@ -158,17 +172,38 @@ __global__ void __launch_bounds__(64, (M > ADF_H_TWO_WAVE_MAX && R > 1) ? 1 : 2)
 
     float a_s[1] = {__shfl_up(c[0][M - 1], 1)};
     if (lane == 0) a_s[0] = 0.0f;
+    if constexpr (NW == 2) {                                     // chunk 64 follows chunk 63
+        if (wv == 0 && lane == 63) xch[0] = c[0][M - 1];
+        __syncthreads();
+        if (wv == 1 && lane == 0) a_s[0] = xch[0];
+    }
 
     Boundary<R> bd[1];
     chunk_boundary<M, R, 1>(c, f0, f1, a_s, bd);
     float nGS0 = __shfl_down(bd[0].GS0, 1), nGS1 = (R > 1) ? __shfl_down(bd[0].GS1, 1) : 0.0f;
     float nPS = __shfl_down(bd[0].PS, 1), nQS = __shfl_down(bd[0].QS, 1);
     if (lane == 63) { nGS0 = 0.0f; nGS1 = 0.0f; nPS = 0.0f; nQS = 0.0f; }
+    if constexpr (NW == 2) {                                     // chunk 63's next chunk is wave 1's first
+        if (wv == 1 && lane == 0) { xch[1] = bd[0].GS0; xch[2] = (R > 1) ? bd[0].GS1 : 0.0f; xch[3] = bd[0].PS; xch[4] = bd[0].QS; }
+        __syncthreads();
+        if (wv == 0 && lane == 63) { nGS0 = xch[1]; nGS1 = xch[2]; nPS = xch[3]; nQS = xch[4]; }
+    }
     float al, be, ga, p0, p1, xs0[1], xs1[1];
     separator_row<M, R>(c[0], f0[0], f1[0], bd[0], nGS0, nGS1, nPS, nQS, al, be, ga, p0, p1);
-    pcr64<R>(lane, al, be, ga, p0, p1, xs0[0], xs1[0]);
-    float xL0[1] = {__shfl_up(xs0[0], 1)}, xL1[1] = {(R > 1) ? __shfl_up(xs1[0], 1) : 0.0f};
-    if (lane == 0) { xL0[0] = 0.0f; xL1[0] = 0.0f; }
+    float xL0[1], xL1[1];
+    if constexpr (NW == 2) {
+        const int g = 64 * wv + lane;                            // chunk of this lane
+        red[0][g] = al; red[1][g] = be; red[2][g] = ga; red[3][g] = p0; red[4][g] = p1;
+        __syncthreads();
+        if (wv == 0) reduced128<R>(lane, red[0], red[1], red[2], red[3], red[4], 1, xsol[0], xsol[1]);
+        __syncthreads();
+        xs0[0] = xsol[0][g]; xs1[0] = (R > 1) ? xsol[1][g] : 0.0f;
+        xL0[0] = g > 0 ? xsol[0][g - 1] : 0.0f; xL1[0] = (R > 1 && g > 0) ? xsol[1][g - 1] : 0.0f;
+    } else {
+        pcr64<R>(lane, al, be, ga, p0, p1, xs0[0], xs1[0]);
+        xL0[0] = __shfl_up(xs0[0], 1); xL1[0] = (R > 1) ? __shfl_up(xs1[0], 1) : 0.0f;
+        if (lane == 0) { xL0[0] = 0.0f; xL1[0] = 0.0f; }
+    }
     chunk_solve<M, R, 1>(c, f0, f1, a_s, xL0, xL1, xs0, xs1);
 
     typedef float v4f __attribute__((ext_vector_type(4)));
@@ -186,7 +221,7 @@ __global__ void __launch_bounds__(64, (M > ADF_H_TWO_WAVE_MAX && R > 1) ? 1 : 2)
 #pragma unroll
         for (int k = 0; k < MQ; k++) {
             const int idx = 64 * k + lane_s;
-            if (idx < nvec) { const float4 q = stage[idx]; const v4f o = {q.x, q.y, q.z, q.w}; __builtin_nontemporal_store(o, d4 + idx); }
+            if (v0 + idx < nvec) { const float4 q = stage[idx]; const v4f o = {q.x, q.y, q.z, q.w}; __builtin_nontemporal_store(o, d4 + v0 + idx); }
         }
     } else {
         // the mirror image of ADF_PAIR_IN: half a row of the pair plane at a time
@@ -205,7 +240,7 @@ __global__ void __launch_bounds__(64, (M > ADF_H_TWO_WAVE_MAX && R > 1) ? 1 : 2)
             __syncthreads();
 #pragma unroll
             for (int k = 0; k < MQ; k++) {
-                const int idx = 64 * (k + half * MQ) + lane_s;
+                const int idx = 2 * v0 + 64 * (k + half * MQ) + lane_s;
                 if (idx < nvecU) { const float4 q = stage[64 * k + lane_s]; const v4f o = {q.x, q.y, q.z, q.w}; __builtin_nontemporal_store(o, d4 + ADF_PIDX(idx)); }
             }
             __syncthreads();
@@ -213,21 +248,21 @@ __global__ void __launch_bounds__(64, (M > ADF_H_TWO_WAVE_MAX && R > 1) ? 1 : 2)
     }
 }
 
-template <int M>
+template <int M, int NW = 1>
 hipError_t launch_h(const WavePassArgs& a, int n_rhs, int n_pairs, hipStream_t st)
 {
-    dim3 grid(a.nscan, n_pairs), block(64);
+    dim3 grid(a.nscan, n_pairs), block(64 * NW);
     if (a.conf_in) {
         if (n_rhs != 2) return hipErrorInvalidValue;
-        hipLaunchKernelGGL((wave_hpass_kernel<M, 2, true>), grid, block, 0, st, a);
-    } else if (n_rhs == 2) hipLaunchKernelGGL((wave_hpass_kernel<M, 2, false>), grid, block, 0, st, a);
-    else hipLaunchKernelGGL((wave_hpass_kernel<M, 1, false>), grid, block, 0, st, a);
+        hipLaunchKernelGGL((wave_hpass_kernel<M, 2, true, NW>), grid, block, 0, st, a);
+    } else if (n_rhs == 2) hipLaunchKernelGGL((wave_hpass_kernel<M, 2, false, NW>), grid, block, 0, st, a);
+    else hipLaunchKernelGGL((wave_hpass_kernel<M, 1, false, NW>), grid, block, 0, st, a);
     return hipGetLastError();
 }
 
 } // namespace
 
-int wave_max_row_len() { return 64 * 64; }
+int wave_max_row_len() { return 128 * 64; }
 
 // The fused first pass reads conf as float4s -- the confidence plane is the library's own and laid out so that the ROI
 // row starts 16-byte aligned whatever the ROI is (Geom::cx0 / cpitch) -- and dL, the caller's map, in 8-byte pieces at
@@ -246,6 +281,14 @@ hipError_t launch_wave_hpass(const WavePassArgs& a, int n_rhs, int n_pairs, hipS
 {
     if (a.len < 2 || a.len > wave_max_row_len() || a.pitch % 64 != 0 || a.pitch < a.len) return hipErrorInvalidValue;
     if (a.conf_in && !wave_hpass_can_fuse(a)) return hipErrorInvalidValue;
+    if (a.len > 64 * 64) {   // wider than 4096 columns: two wavefronts per row
+        const int m = (a.len + 127) / 128;
+        if (m <= 40) return launch_h<40, 2>(a, n_rhs, n_pairs, st);
+        if (m <= 48) return launch_h<48, 2>(a, n_rhs, n_pairs, st);
+        if (m <= 56) return launch_h<56, 2>(a, n_rhs, n_pairs, st);
+        if (m <= 60) return launch_h<60, 2>(a, n_rhs, n_pairs, st);   // 7680 columns: a full 8K row
+        return launch_h<64, 2>(a, n_rhs, n_pairs, st);
+    }
     const int m = (a.len + 63) / 64;
     if (m <= 4) return launch_h<4>(a, n_rhs, n_pairs, st);
     if (m <= 8) return launch_h<8>(a, n_rhs, n_pairs, st);

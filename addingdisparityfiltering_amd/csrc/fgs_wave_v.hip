@@ -40,7 +40,12 @@ using namespace wave;
 // thread = (chunk cidx in [0,64), column pair xp in [0,8)); M rows x 2 columns per thread.
 // ---------------------------------------------------------------------------------------------
 constexpr int VT = 512;  // threads per strip
-constexpr int VC = 16;   // columns per strip
+constexpr int VC = 16;   // columns per strip (the layouts' strip: fgs_wave_common.h)
+// Round 3: columns longer than 64 chunks of 34 rows (ROIs taller than 2176 rows: 8K frames) run HALF strips of 128 chunks
+// -- VCW = 8 columns, NCH = 128, still 512 threads and the same rows and registers per thread, i.e. the same 415 KB of a
+// CU's register file per workgroup -- with a 128-row reduced system per column (fgs_wave_common.h, reduced128).  Half
+// strips read 32-byte pieces (a quarter less bandwidth on a full chip, tools/micro/vpattern.hip), still well ahead of
+// the exact solver such ROIs fell back to.  Everything below is written for VCW columns x NCH chunks.
 
 // ---------------------------------------------------------------------------------------------
 // Whole-line loads by LDS-DMA (round 3; NOT the default: -DADF_V_GLDS=1 selects it).  Moving the pass's bytes alone
@@ -159,15 +164,18 @@ __device__ __forceinline__ unsigned epi_pack16(v2f u0, v2f u1)
     return __builtin_bit_cast(unsigned, (s2)__builtin_amdgcn_cvt_pk_i16(i0, i1));
 }
 
-template <int M, int R, int EPI>
+template <int M, int R, int EPI, int VCW = VC, int NCH = 64>
 __global__ void __launch_bounds__(VT) wave_vpass_kernel(WavePassArgs a)
 {
-    __shared__ float nb[4][64][VC];   // next-chunk exchange: GS0, GS1, PS, QS
-    __shared__ float red[5][VC][64];  // separator rows by (column, chunk)
-    __shared__ float xs[2][VC][64];   // separator solutions
+    static_assert((VCW == 16 && NCH == 64) || (VCW == 8 && NCH == 128), "whole strips of 64 chunks or half strips of 128");
+    static_assert((VCW / 2) * NCH == VT, "one thread per (chunk, column pair)");
+    constexpr int XPN = VCW / 2;         // column pairs per workgroup
+    __shared__ float nb[4][NCH][VCW];   // next-chunk exchange: GS0, GS1, PS, QS
+    __shared__ float red[5][VCW][NCH];  // separator rows by (column, chunk)
+    __shared__ float xs[2][VCW][NCH];   // separator solutions
     extern __shared__ __align__(16) char vring[];   // R == 2: 8 waves x VRing<M>::SLOTS KiB (LDS-DMA landing zone)
     const int tid = threadIdx.x;
-    const int xp = tid & 7, cidx = tid >> 3;
+    const int xp = tid & (XPN - 1), cidx = tid / XPN;
 #ifdef ADF_V_STAGGER
     // Experiment (tools/vstagger.sh): every workgroup of a pass runs the same program for the same time, so the CUs
     // stay in step -- all loading, then all computing.  Delay the first round's workgroups by a fraction of the
@@ -191,8 +199,8 @@ __global__ void __launch_bounds__(VT) wave_vpass_kernel(WavePassArgs a)
     // b+8, b+16, b+24 are dealt to the same XCD back to back (speed only, never correctness), so four
     // consecutive strips are mapped to them: later requests for a line hit (or merge in) that XCD's L2
     // instead of going to the fabric again, and partial-line writes combine there before eviction.
-    int strip = blockIdx.x;
-    {
+    int strip = VCW == VC ? (int)blockIdx.x : (int)(blockIdx.x >> 1);   // the layouts' 16-column strip this workgroup works in
+    if (VCW == VC) {
         const int nfull = (int)(gridDim.x / 32) * 32;
         // (round 3: only the passes that WRITE partial lines are remapped -- the plain pass of two right-hand sides reads
         // and writes whole lines, and with consecutive blocks on consecutive strips it runs 4 % faster)
@@ -201,7 +209,8 @@ __global__ void __launch_bounds__(VT) wave_vpass_kernel(WavePassArgs a)
             strip = (grp << 5) + ((w & 7) << 2) + (w >> 3);
         }
     }
-    const int col = strip * VC + 2 * xp;             // < pitch by construction of the grid
+    const unsigned c16 = 2u * (unsigned)xp + (VCW == VC ? 0u : 8u * (blockIdx.x & 1u));   // the thread's first column inside the strip
+    const int col = strip * VC + (int)c16;           // < pitch by construction of the grid
     const size_t pb = (size_t)blockIdx.y * a.plane;
     const int r0 = cidx * M;
     const int h = a.len;                            // scanline length = ROI height
@@ -223,20 +232,20 @@ __global__ void __launch_bounds__(VT) wave_vpass_kernel(WavePassArgs a)
     constexpr unsigned TR = ADF_TILE_ROWS;
     const unsigned tile_b = 2u * TR * (unsigned)a.pitch * 4u;            // bytes from a tile to the next one
 #define ADF_VSTEP(i) ((R > 1) ? (((((unsigned)r0 + (unsigned)(i) + 1u) & (TR - 1u)) == 0u) ? tile_b - (TR - 1u) * 128u : 128u) : pitch_b)
-    const unsigned voff0 = (R > 1) ? (((unsigned)r0 / TR) * (2u * TR * (unsigned)a.pitch) + (unsigned)strip * (32u * TR) + ((unsigned)r0 % TR) * 32u + 2u * xp) * 4u
+    const unsigned voff0 = (R > 1) ? (((unsigned)r0 / TR) * (2u * TR * (unsigned)a.pitch) + (unsigned)strip * (32u * TR) + ((unsigned)r0 % TR) * 32u + c16) * 4u
                                    : ((unsigned)r0 * (unsigned)a.pitch + (unsigned)col) * 4u;
     const unsigned pitch_c = 4u * VC;
-    const unsigned coff0 = (((unsigned)strip * (unsigned)h + (unsigned)r0) * VC + 2u * xp) * 4u;
+    const unsigned coff0 = (((unsigned)strip * (unsigned)h + (unsigned)r0) * VC + c16) * 4u;
 
     // both columns of a row in one register pair, from the 8-byte load to the 8-byte store (see the
     // two-column templates in fgs_wave_common.h)
     v2f c[M], f0[M], f1[M];
     // row 0 of the column: always inside the planes
-    const unsigned safe = (R > 1) ? ((unsigned)strip * (32u * TR) + 2u * xp) * 4u : (unsigned)col * 4u;
-    const unsigned csafe = ((unsigned)strip * (unsigned)h * VC + 2u * xp) * 4u;
+    const unsigned safe = (R > 1) ? ((unsigned)strip * (32u * TR) + c16) * 4u : (unsigned)col * 4u;
+    const unsigned csafe = ((unsigned)strip * (unsigned)h * VC + c16) * 4u;
     v2f a_s = vsplat(0.0f);
     if (cidx > 0 && r0 - 1 < h) a_s = *reinterpret_cast<const v2f*>(bC + (coff0 - pitch_c)) * vsplat(a.lambda);
-    if constexpr (R > 1 && ADF_V_GLDS) {
+    if constexpr (R > 1 && ADF_V_GLDS && VCW == VC) {
         // Rows past the end of the column are fetched from row 0 of the same strip (always inside the planes) and NOT
         // masked: Cvert is 0 in the last row (FGS.cpp:658-660), so whatever finite, diagonally dominant system those
         // rows form is decoupled from the real one by exact zeros (0 * finite), and the stores below skip them.
@@ -294,7 +303,7 @@ __global__ void __launch_bounds__(VT) wave_vpass_kernel(WavePassArgs a)
     __syncthreads();
     {
         v2f nGS0 = vsplat(0.f), nGS1 = nGS0, nPS = nGS0, nQS = nGS0;
-        if (cidx < 63) {
+        if (cidx < NCH - 1) {
             nGS0 = *reinterpret_cast<const v2f*>(&nb[0][cidx + 1][2 * xp]); nGS1 = *reinterpret_cast<const v2f*>(&nb[1][cidx + 1][2 * xp]);
             nPS = *reinterpret_cast<const v2f*>(&nb[2][cidx + 1][2 * xp]); nQS = *reinterpret_cast<const v2f*>(&nb[3][cidx + 1][2 * xp]);
         }
@@ -306,7 +315,7 @@ __global__ void __launch_bounds__(VT) wave_vpass_kernel(WavePassArgs a)
         red[3][2 * xp + 1][cidx] = p0.y; red[4][2 * xp + 1][cidx] = p1.y;
     }
     __syncthreads();
-    {   // 8 wavefronts x 2 columns each: one separator row per lane
+    if constexpr (NCH == 64) {   // 8 wavefronts x 2 columns each: one separator row per lane
         const int wv = tid >> 6, lane = tid & 63;
 #pragma unroll
         for (int e = 0; e < 2; e++) {
@@ -315,6 +324,9 @@ __global__ void __launch_bounds__(VT) wave_vpass_kernel(WavePassArgs a)
             pcr64<R>(lane, red[0][cc][lane], red[1][cc][lane], red[2][cc][lane], red[3][cc][lane], red[4][cc][lane], x0, x1);
             xs[0][cc][lane] = x0; xs[1][cc][lane] = x1;
         }
+    } else {                     // 8 wavefronts, one column each: a 128-row system, two rows per lane
+        const int cc = tid >> 6, lane = tid & 63;
+        reduced128<R>(lane, red[0][cc], red[1][cc], red[2][cc], red[3][cc], red[4][cc], 1, xs[0][cc], xs[1][cc]);
     }
     __syncthreads();
     {
@@ -428,19 +440,19 @@ hipError_t v_allow_lds(K kernel, size_t bytes)
     return e;
 }
 
-template <int M>
+template <int M, int VCW = VC, int NCH = 64>
 hipError_t launch_v(const WavePassArgs& a, int n_rhs, int epi, int n_pairs, hipStream_t st)
 {
-    dim3 grid(a.pitch / VC, n_pairs), block(VT);
+    dim3 grid(a.pitch / VCW, n_pairs), block(VT);
     const size_t ring = (size_t)(VT / 64) * VRing<M>::SLOTS * 1024;
 #define ADF_LV(RR, EE)                                                                                        \
     do {                                                                                                      \
-        const size_t lds = ((RR) > 1 && ADF_V_GLDS) ? ring : 0;                                               \
+        const size_t lds = ((RR) > 1 && ADF_V_GLDS && VCW == VC) ? ring : 0;                                  \
         if (lds > 16 * 1024) {                                                                                \
-            hipError_t e = v_allow_lds(wave_vpass_kernel<M, RR, EE>, lds);                                    \
+            hipError_t e = v_allow_lds(wave_vpass_kernel<M, RR, EE, VCW, NCH>, lds);                          \
             if (e != hipSuccess) return e;                                                                    \
         }                                                                                                     \
-        hipLaunchKernelGGL((wave_vpass_kernel<M, RR, EE>), grid, block, lds, st, a);                          \
+        hipLaunchKernelGGL((wave_vpass_kernel<M, RR, EE, VCW, NCH>), grid, block, lds, st, a);                \
     } while (0)
     if (n_rhs == 2 && epi == EPI_PLANES) ADF_LV(2, EPI_PLANES);
     else if (n_rhs == 2 && epi == EPI_WLS_CONF) ADF_LV(2, EPI_WLS_CONF);
@@ -458,11 +470,17 @@ hipError_t launch_v(const WavePassArgs& a, int n_rhs, int epi, int n_pairs, hipS
 
 } // namespace
 
-int wave_max_col_len() { return 64 * 34; }
+int wave_max_col_len() { return 128 * 34; }
 
 hipError_t launch_wave_vpass(const WavePassArgs& a, int n_rhs, int epilogue, int n_pairs, hipStream_t st)
 {
     if (a.len < 2 || a.len > wave_max_col_len() || a.pitch % 64 != 0 || a.pitch < a.nscan) return hipErrorInvalidValue;
+    if (a.len > 64 * 34) {   // taller than 2176 rows: half strips of 128 chunks
+        const int m = (a.len + 127) / 128;
+        if (m <= 20) return launch_v<20, VC / 2, 128>(a, n_rhs, epilogue, n_pairs, st);
+        if (m <= 26) return launch_v<26, VC / 2, 128>(a, n_rhs, epilogue, n_pairs, st);
+        return launch_v<34, VC / 2, 128>(a, n_rhs, epilogue, n_pairs, st);
+    }
     const int m = (a.len + 63) / 64;
     if (m <= 2) return launch_v<2>(a, n_rhs, epilogue, n_pairs, st);
     if (m <= 4) return launch_v<4>(a, n_rhs, epilogue, n_pairs, st);

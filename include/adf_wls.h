@@ -110,8 +110,9 @@ int adf_wls_get_depth_discontinuity_radius(const adf_wls_t* h, int* radius);
 int adf_wls_set_fgs_params(adf_wls_t* h, double lambda_attenuation, int num_iter);
 int adf_wls_set_solver(adf_wls_t* h, int solver);
 int adf_wls_get_solver(const adf_wls_t* h, int* solver);
-/* Solver the last filter call actually ran: ADF_SOLVER_WAVE covers ROIs up to 4096 x 2176; larger
- * ones fall back to ADF_SOLVER_EXACT. */
+/* Solver the last filter call actually ran: ADF_SOLVER_WAVE covers ROIs up to 8192 x 4352 (an 8K frame: beyond 4096
+ * columns two wavefronts share a row, beyond 2176 rows a column is cut into 128 chunks); larger ones fall back to
+ * ADF_SOLVER_EXACT. */
 int adf_wls_get_last_solver(const adf_wls_t* h, int* solver);
 /* Which kernels the confidence stage of the last filter call took (introspection for tests and benchmarks; the
  * results do not depend on it): ADF_PATH_CONF_BAND = computeConfidenceMap (DF.cpp:197-210) ran as the one-sweep band

@@ -157,7 +157,9 @@ def test_batch_equals_singles_and_full_width(adf, oracle):
 # every chunk-length bucket of the row pass (fgs_wave_h.hip: 4..64 elements per lane), at a width that fills
 # it and at one just past the previous bucket, with an ROI the fused first pass accepts (x, width multiples
 # of 4) and one it must refuse (odd x / width: the pair plane is then written by the confidence kernel)
-@pytest.mark.parametrize("width", [256, 260, 512, 1024, 1100, 1280, 1792, 2500, 2560, 3584, 3700, 3840, 3844, 4096])
+# (round 3: beyond 4096 columns two wavefronts share a row -- 128 chunks of 40..64 elements, a 128-row reduced system)
+@pytest.mark.parametrize("width", [256, 260, 512, 1024, 1100, 1280, 1792, 2500, 2560, 3584, 3700, 3840, 3844, 4096,
+                                   4100, 5120, 5124, 6144, 7168, 7680, 7700, 8192])
 @pytest.mark.parametrize("fusable", [True, False])
 def test_every_row_bucket(adf, oracle, width, fusable):
     h = 40
@@ -169,7 +171,9 @@ def test_every_row_bucket(adf, oracle, width, fusable):
 
 # every chunk-length bucket of the column pass (fgs_wave_v.hip: 2..34 rows per thread), columns that end
 # inside a chunk, exactly on a chunk boundary, and that leave whole chunks empty
-@pytest.mark.parametrize("height", [3, 128, 129, 200, 256, 500, 512, 700, 768, 1100, 1152, 1600, 1664, 2000, 2160, 2176])
+# (round 3: beyond 2176 rows half strips of 128 chunks -- 20, 26 or 34 rows per thread)
+@pytest.mark.parametrize("height", [3, 128, 129, 200, 256, 500, 512, 700, 768, 1100, 1152, 1600, 1664, 2000, 2160, 2176,
+                                    2177, 2300, 2560, 2600, 3328, 3400, 4320, 4352])
 def test_every_column_bucket(adf, oracle, height):
     w = 96
     view, dl, dr, roi = synthetic.make_artificial_example(w, height, 3, seed=height, rect_disparity=16)
@@ -181,14 +185,25 @@ def test_every_column_bucket(adf, oracle, height):
 
 
 def test_falls_back_to_exact_beyond_register_capacity(adf, oracle):
-    """Columns longer than 2176 rows do not fit the register-resident strip: exact solver takes over."""
-    view, dl, dr, roi = synthetic.make_artificial_example(96, 2300, 1, seed=4, rect_disparity=10)
+    """Columns longer than 4352 rows (128 chunks of 34) do not fit the register-resident strips: exact solver takes over."""
+    view, dl, dr, roi = synthetic.make_artificial_example(96, 4400, 1, seed=4, rect_disparity=10)
     f = adf.createDisparityWLSFilterGeneric(True)
     f.setSolver(adf.SOLVER_WAVE)
     got = f.filter(dl, view, None, dr, roi)
     assert f.getLastSolver() == adf.SOLVER_EXACT
     exp, _ = oracle.wls_filter(dl, view, dr, roi, oracle.default_params(threads=8))
     assert np.array_equal(got, exp)
+
+
+def test_8k_pair_on_the_wave_solver(adf, oracle):
+    """A 7680x4320 pair (round 3): two wavefronts per row, half strips of 128 chunks per column -- the reference's bar."""
+    w, h = 7680, 4320
+    view, dl, dr, roi = synthetic.make_artificial_example(w, h, 3, seed=88, rect_disparity=256)
+    diff, got, exp = _run(adf, oracle, dl, view, dr, roi, **{"lambda": 8000.0, "sigma_color": 1.5, "disc_radius": 2})
+    assert diff.max() <= MAX_DIF and diff.mean() <= MAX_MEAN_DIF, (diff.max(), diff.mean())
+    # and without the confidence maps: one right-hand side, plain planes
+    diff, _, _ = _run(adf, oracle, dl, view, dr, roi, use_conf=False, **{"sigma_color": 1.5})
+    assert diff.max() <= MAX_DIF and diff.mean() <= MAX_MEAN_DIF, (diff.max(), diff.mean())
 
 
 def test_switching_solvers_on_one_handle(adf, oracle):
