@@ -1,0 +1,18 @@
+#!/bin/bash
+# Round 3: where do the waves of each kernel spend their cycles?  SQ / TA counters of one sequential 8-pair step
+# (ADF_NO_OVERLAP=1: no two kernels of the call share the chip), one rocprofv3 pass per counter group.
+#   gpurun --timeout 900 -- 'bash profiles/collect_pmc_sq.sh'
+set -e
+cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
+export ADF_NO_OVERLAP=1
+args="bench.py --pairs 8 --steps 1 --warmup 1 --cpu-seconds 0 --no-check --matcher-pairs 0 --natural-pairs 0"
+i=0
+for grp in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_LDS" \
+           "SQ_INST_CYCLES_VMEM_WR SQ_INST_CYCLES_VMEM_RD SQ_VMEM_WR_TA_DATA_FIFO_FULL SQ_VMEM_TA_ADDR_FIFO_FULL SQ_VMEM_TA_CMD_FIFO_FULL SQ_INST_LEVEL_VMEM SQ_WAVES SQ_ACTIVE_INST_SCA"; do
+  # (a third pass with TA_* counters aborted inside rocprofv3 on this image and hung the call: not collected)
+  i=$((i+1))
+  rm -rf gpurun_out/r03_sq_$i
+  rocprofv3 --kernel-trace --pmc $grp -d gpurun_out/r03_sq_$i -o pmc --output-format csv -- python3 $args > gpurun_out/r03_sq_$i.log 2>&1
+done
+python3 profiles/summarize_pmc_sq.py > gpurun_out/r03_pmc_sq.txt
+cat gpurun_out/r03_pmc_sq.txt
