@@ -690,9 +690,16 @@ def build_line(args, dry, world, backend, n_total, pairs, W, H, ch, roi, roi_kin
     def bucket(v, bs):
         return next(b for b in bs if v <= b)
     if args.solver == "wave":
-        mh = bucket((roi[2] + 63) // 64, (4, 8, 16, 20, 28, 40, 56, 60, 64))
-        mv = bucket((roi[3] + 63) // 64, (2, 4, 8, 12, 18, 26, 34))
-        names = {"pass_h": "wave_hpass_kernel<%d, 2, false>" % mh, "pass_v": "wave_vpass_kernel<%d, 2, 0>" % mv}
+        # (rows beyond 4096 columns: two wavefronts per row; columns beyond 2176 rows: half strips of 128 chunks)
+        if roi[2] > 4096:
+            hname = "wave_hpass_kernel<%d, 2, false, 2>" % bucket((roi[2] + 127) // 128, (40, 48, 56, 60, 64))
+        else:
+            hname = "wave_hpass_kernel<%d, 2, false, 1>" % bucket((roi[2] + 63) // 64, (4, 8, 16, 20, 28, 40, 56, 60, 64))
+        if roi[3] > 2176:
+            vname = "wave_vpass_kernel<%d, 2, 0, 8, 128>" % bucket((roi[3] + 127) // 128, (20, 26, 34))
+        else:
+            vname = "wave_vpass_kernel<%d, 2, 0, 16, 64>" % bucket((roi[3] + 63) // 64, (2, 4, 8, 12, 18, 26, 34))
+        names = {"pass_h": hname, "pass_v": vname}
     else:
         names = {"pass_h": "exact_pass_kernel<2, 0>", "pass_v": "exact_pass_kernel<2, 0>"}
 
