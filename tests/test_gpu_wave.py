@@ -415,3 +415,20 @@ def test_confidence_decaying_into_denormals(adf, oracle):
     assert tiny.sum() >= 50, tiny.sum()
     assert (np.abs(exp[y:y + h, x:x + w][tiny].astype(np.int32) - 320) <= 2).all()
     assert diff.max() <= MAX_DIF, diff.max()
+
+
+def test_more_sigmas_than_cached_tables(adf, oracle):
+    """A handle keeps eight weight tables; the ninth sigma evicts the least recently used one, and coming back to an
+    evicted sigma rebuilds it -- results must not depend on the history."""
+    view, dl, dr, roi, radius = synthetic.make_config_example(1)
+    f = adf.createDisparityWLSFilterGeneric(True)
+    f.setSolver(adf.SOLVER_EXACT); f.setDepthDiscontinuityRadius(radius)
+    sigmas = [0.5 + 0.7 * k for k in range(11)]
+    for sig in sigmas + [sigmas[0], sigmas[5], sigmas[10]]:
+        f.setSigmaColor(sig)
+        got = f.filter(dl, view, None, dr, roi)
+    for sig in (sigmas[0], sigmas[10]):
+        f.setSigmaColor(sig)
+        got = f.filter(dl, view, None, dr, roi)
+        exp, _ = oracle.wls_filter(dl, view, dr, roi, oracle.default_params(sigma_color=sig, disc_radius=radius, threads=8))
+        assert np.array_equal(got, exp), sig
