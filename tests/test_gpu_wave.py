@@ -432,3 +432,35 @@ def test_more_sigmas_than_cached_tables(adf, oracle):
         got = f.filter(dl, view, None, dr, roi)
         exp, _ = oracle.wls_filter(dl, view, dr, roi, oracle.default_params(sigma_color=sig, disc_radius=radius, threads=8))
         assert np.array_equal(got, exp), sig
+
+
+@pytest.mark.parametrize("size", [(3840, 2160), (7680, 4320)])
+def test_size_independent_properties_at_full_size(adf, size):
+    """Properties of the smoother that hold at any size, on BASELINE's 4K frame and on an 8K one (no oracle call):
+    the operator is LINEAR in its source -- scaling the source by a power of two scales every intermediate exactly, so
+    the result must scale bit for bit, whatever the chunking --, it preserves constants, it never leaves the range of
+    its source (every pass is a convex combination: the matrices are M-matrices with unit row sums), and mirroring guide
+    and source mirrors the result up to the re-association of the mirrored chunks."""
+    import torch
+
+    W, H = size
+    dev = torch.device("cuda:0")
+    gen = torch.Generator(device=dev); gen.manual_seed(3)
+    guide = torch.randint(0, 256, (H, W, 3), generator=gen, device=dev, dtype=torch.uint8)
+    guide = (guide // 32 * 32).contiguous()                         # piecewise-flat guide: strong coupling
+    src = (torch.randn((H, W), generator=gen, device=dev) * 200.0).contiguous()
+    for solver in (adf.SOLVER_WAVE, adf.SOLVER_EXACT):
+        f = adf.createFastGlobalSmootherFilter(guide, 2000.0, 10.0, solver=solver)
+        a = f.filter(src).clone()
+        b = f.filter(src * 4.0).clone()
+        assert torch.equal(b, a * 4.0), "not linear in the source"                      # bit for bit
+        slack = 1e-3 * float(src.abs().max())                       # (float32 at a condition number of ~4 * lambda)
+        assert float(a.min()) >= float(src.min()) - slack and float(a.max()) <= float(src.max()) + slack
+        c = f.filter(torch.full_like(src, 37.5))
+        assert float((c - 37.5).abs().max()) <= 37.5e-3 and float((c - 37.5).abs().mean()) <= 37.5e-4
+        fm = adf.createFastGlobalSmootherFilter(torch.flip(guide, dims=(1,)).contiguous(), 2000.0, 10.0, solver=solver)
+        m = torch.flip(fm.filter(torch.flip(src, dims=(1,)).contiguous()), dims=(1,))
+        tol = 1e-4 * float(src.abs().max())
+        assert float((m - a).abs().max()) <= tol, float((m - a).abs().max())
+        del f, fm
+    torch.cuda.empty_cache()
