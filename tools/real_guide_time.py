@@ -61,6 +61,11 @@ def main(pairs=16):
         100.0 * (((g1[0, :, 1:].int() - g1[0, :, :-1].int()) ** 2) >= 2048).float().mean().item()))
     run("KITTI tiled, 3 channels", g3, dl, dr, roi, radius)
     run("KITTI tiled, 1 channel", g1, dl, dr, roi, radius)
+    # the worst case for the table: white noise -- nearly every index lies beyond the head cached in LDS
+    noise = torch.randint(0, 256, (pairs, H, W, 3), generator=gen, device=dev, dtype=torch.uint8)
+    dn = ((noise[0, :, 1:].int() - noise[0, :, :-1].int()) ** 2).sum(-1)
+    print("white-noise guide: %.1f %% of the horizontal table indices are >= 2048" % (100.0 * (dn >= 2048).float().mean().item()))
+    run("white noise, 3 channels", noise, dl, dr, roi, radius)
 
 
 if __name__ == "__main__":
