@@ -14,6 +14,7 @@
 // All of this is integer / elementwise float work: HBM-bound, no MFMA.  Arithmetic that must
 // match the CPU restatement bit for bit is written as separate roundings (contraction off).
 #include "adf_internal.h"
+#include <cstdlib>
 #include "prep_bodies.h"
 
 #pragma clang fp contract(off)
@@ -880,11 +881,32 @@ hipError_t launch_conf_band(const ConfBandArgs& a0, int n_pairs, hipStream_t st)
     if (!conf_band_fits(a0.g, a0.radius)) return hipErrorInvalidValue;
     ConfBandArgs a = a0;
     const int waves = (a.g.rw + CB_WOUT(a.radius) - 1) / CB_WOUT(a.radius);
-    // bands: tall (the 2*RT halo rows and the K-row ramp are paid per band), but enough workgroups for two rounds
-    // of the chip's 256 CUs when the batch allows it.  A band is walked row by row (one workgroup barrier per row,
-    // ~1.3 us each): with few pairs per call the band height IS the kernel's latency (one 1242x375 frame in 32-row
-    // bands: 12 workgroups, 47 us), so small calls get bands down to max(4, 2 * radius) rows (round 3).
-    int bands = (512 + n_pairs - 1) / n_pairs;
+    // bands: at most ONE workgroup per CU, on three quarters of the CUs (round 3; it was two rounds of the chip).  A band workgroup is 15 waves with 57 KB of
+    // LDS: it only starts on a CU that has all of that free at once, and the weight kernel that runs beside this one on
+    // the side stream refills every slot a finished band leaves with its own small workgroups -- the second round's
+    // bands then queue until the weight kernel is done (kernel timeline: this kernel 2.38 ms beside it, 1.32 alone).
+    // With no more bands than CUs every band starts at once and runs through: 1.39-1.43 ms beside the weight kernel, the
+    // pair 2.19-2.22 ms instead of 2.46.  A band is walked row by row (one workgroup barrier per row, ~1.3 us each): with
+    // few pairs per call the band height IS the kernel's latency (one 1242x375 frame in 32-row bands: 12 workgroups,
+    // 47 us), so small calls get bands down to max(4, 2 * radius) rows.
+    static const int bands_env = [] { const char* e = getenv("ADF_CONF_BANDS_TOTAL"); return e ? atoi(e) : 0; }();   // A/B knob
+    int bands_total = bands_env;
+    // (radii 3..8 take 104..128 registers: four of their waves fill a SIMD's register file, nothing runs beside them
+    // whatever the schedule -- they keep two rounds of shorter bands, which measured 0.1-0.2 ms better there)
+    if (bands_total <= 0 && a.radius > 2) bands_total = 512;
+    if (bands_total <= 0) {
+        static int cu_count[64] = {0};                        // per device, read once (racing writers store the same value)
+        int dev = 0, cus = 0;
+        if (hipGetDevice(&dev) != hipSuccess) dev = -1;
+        if (dev >= 0 && dev < 64) cus = __atomic_load_n(&cu_count[dev], __ATOMIC_RELAXED);
+        if (cus <= 0) {
+            if (dev < 0 || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
+            if (dev >= 0 && dev < 64) __atomic_store_n(&cu_count[dev], cus, __ATOMIC_RELAXED);
+        }
+        bands_total = cus * 3 / 4;   // (a quarter of the CUs left to the weight kernel alone: both finish together -- 1.82 / 1.92 ms
+                                     //  instead of 1.35 / 2.0 with a band on every CU; the step 13.12-13.18 -> 13.04-13.09 ms)
+    }
+    int bands = (bands_total + n_pairs - 1) / n_pairs;
     int rpb = (a.g.rh + bands - 1) / bands;
     const int min_rpb = 2 * a.radius > 4 ? 2 * a.radius : 4;     // (at least as many output rows as halo rows)
     if (rpb < min_rpb) rpb = min_rpb;
