@@ -891,9 +891,6 @@ hipError_t launch_conf_band(const ConfBandArgs& a0, int n_pairs, hipStream_t st)
     // 47 us), so small calls get bands down to max(4, 2 * radius) rows.
     static const int bands_env = [] { const char* e = getenv("ADF_CONF_BANDS_TOTAL"); return e ? atoi(e) : 0; }();   // A/B knob
     int bands_total = bands_env;
-    // (radii 3..8 take 104..128 registers: four of their waves fill a SIMD's register file, nothing runs beside them
-    // whatever the schedule -- they keep two rounds of shorter bands, which measured 0.1-0.2 ms better there)
-    if (bands_total <= 0 && a.radius > 2) bands_total = 512;
     if (bands_total <= 0) {
         static int cu_count[64] = {0};                        // per device, read once (racing writers store the same value)
         int dev = 0, cus = 0;
@@ -903,8 +900,11 @@ hipError_t launch_conf_band(const ConfBandArgs& a0, int n_pairs, hipStream_t st)
             if (dev < 0 || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
             if (dev >= 0 && dev < 64) __atomic_store_n(&cu_count[dev], cus, __ATOMIC_RELAXED);
         }
-        bands_total = cus * 3 / 4;   // (a quarter of the CUs left to the weight kernel alone: both finish together -- 1.82 / 1.92 ms
-                                     //  instead of 1.35 / 2.0 with a band on every CU; the step 13.12-13.18 -> 13.04-13.09 ms)
+        // a quarter of the CUs left to the weight kernel (and the fill) alone: radius 2 -- both finish together, 1.82 / 1.92 ms
+        // instead of 1.35 / 2.0 with a band on every CU, the step 13.12-13.18 -> 13.04-13.09 ms; radius 3 -- 13.55-13.78 ->
+        // 13.09-13.13 ms; radius 5 on the StereoBM factory's ROI -- 13.87-14.16 -> 13.69-13.96 (the band kernels of radius 4..8
+        // fill a SIMD's registers with four waves: nothing runs BESIDE them, but the fill no longer crawls behind them)
+        bands_total = cus * 3 / 4;
     }
     int bands = (bands_total + n_pairs - 1) / n_pairs;
     int rpb = (a.g.rh + bands - 1) / bands;
