@@ -904,7 +904,17 @@ hipError_t launch_conf_band(const ConfBandArgs& a0, int n_pairs, hipStream_t st)
         // instead of 1.35 / 2.0 with a band on every CU, the step 13.12-13.18 -> 13.04-13.09 ms; radius 3 -- 13.55-13.78 ->
         // 13.09-13.13 ms; radius 5 on the StereoBM factory's ROI -- 13.87-14.16 -> 13.69-13.96 (the band kernels of radius 4..8
         // fill a SIMD's registers with four waves: nothing runs BESIDE them, but the fill no longer crawls behind them)
-        bands_total = cus * 3 / 4;
+        // (narrow ROIs make small band workgroups, several of which share a CU: count those -- registers per radius as
+        // compiled (83..128: tools/isa_stats.sh), allocated in granules of 8; 256 frames of 1242x375 per call lost 6 % with
+        // one tall band per frame)
+        static const int regs_by_radius[9] = {0, 83, 90, 104, 114, 122, 128, 128, 128};
+        const int alloc = (regs_by_radius[a.radius] + 7) / 8 * 8;
+        int per_simd = 512 / alloc; if (per_simd > 8) per_simd = 8;
+        int per_cu = 4 * per_simd / waves;
+        const int by_lds = (int)((size_t)160 * 1024 / (conf_band_lds(a.g.rw, a.radius) + 1024));
+        if (per_cu > by_lds) per_cu = by_lds;
+        if (per_cu < 1) per_cu = 1;
+        bands_total = cus * 3 / 4 * per_cu;
     }
     int bands = (bands_total + n_pairs - 1) / n_pairs;
     int rpb = (a.g.rh + bands - 1) / bands;
