@@ -14,6 +14,7 @@
 // All of this is integer / elementwise float work: HBM-bound, no MFMA.  Arithmetic that must
 // match the CPU restatement bit for bit is written as separate roundings (contraction off).
 #include "adf_internal.h"
+#include <mutex>
 #include <cstdlib>
 #include "prep_bodies.h"
 
@@ -876,6 +877,28 @@ bool conf_band_fits(const Geom& g, int radius)
            g.rh > radius && conf_band_lds(g.rw, radius) <= 150 * 1024;
 }
 
+// Band workgroups of this shape a CU holds at once (occupancy query, remembered per radius for the last shape asked).
+static int conf_band_resident(int radius, int threads, size_t lds, int dev)
+{
+    struct Memo { int dev, threads; size_t lds; int value; };
+    static Memo memo[CB_MAX_RADIUS + 1] = {};
+    static std::mutex mu;
+    {
+        std::lock_guard<std::mutex> lk(mu);
+        const Memo& m = memo[radius];
+        if (m.value > 0 && m.dev == dev && m.threads == threads && m.lds == lds) return m.value;
+    }
+    int v = 0;
+    hipError_t e = hipErrorInvalidValue;
+#define ADF_CBQ(RR) case RR: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&v, conf_band_kernel<RR>, threads, lds); break;
+    switch (radius) { ADF_CBQ(1) ADF_CBQ(2) ADF_CBQ(3) ADF_CBQ(4) ADF_CBQ(5) ADF_CBQ(6) ADF_CBQ(7) ADF_CBQ(8) }
+#undef ADF_CBQ
+    if (e != hipSuccess || v < 1) { (void)hipGetLastError(); v = 1; }
+    std::lock_guard<std::mutex> lk(mu);
+    memo[radius] = Memo{dev, threads, lds, v};
+    return v;
+}
+
 hipError_t launch_conf_band(const ConfBandArgs& a0, int n_pairs, hipStream_t st)
 {
     if (!conf_band_fits(a0.g, a0.radius)) return hipErrorInvalidValue;
@@ -904,15 +927,9 @@ hipError_t launch_conf_band(const ConfBandArgs& a0, int n_pairs, hipStream_t st)
         // instead of 1.35 / 2.0 with a band on every CU, the step 13.12-13.18 -> 13.04-13.09 ms; radius 3 -- 13.55-13.78 ->
         // 13.09-13.13 ms; radius 5 on the StereoBM factory's ROI -- 13.87-14.16 -> 13.69-13.96 (the band kernels of radius 4..8
         // fill a SIMD's registers with four waves: nothing runs BESIDE them, but the fill no longer crawls behind them)
-        // (narrow ROIs make small band workgroups, several of which share a CU: count those -- registers per radius as
-        // compiled (83..128: tools/isa_stats.sh), allocated in granules of 8; 256 frames of 1242x375 per call lost 6 % with
-        // one tall band per frame)
-        static const int regs_by_radius[9] = {0, 83, 90, 104, 114, 122, 128, 128, 128};
-        const int alloc = (regs_by_radius[a.radius] + 7) / 8 * 8;
-        int per_simd = 512 / alloc; if (per_simd > 8) per_simd = 8;
-        int per_cu = 4 * per_simd / waves;
-        const int by_lds = (int)((size_t)160 * 1024 / (conf_band_lds(a.g.rw, a.radius) + 1024));
-        if (per_cu > by_lds) per_cu = by_lds;
+        // (narrow ROIs make small band workgroups, several of which share a CU: ask the runtime how many -- 256 frames of
+        // 1242x375 per call lost 6 % with one tall band per frame)
+        int per_cu = conf_band_resident(a.radius, 64 * waves, conf_band_lds(a.g.rw, a.radius), dev);
         if (per_cu < 1) per_cu = 1;
         bands_total = cus * 3 / 4 * per_cu;
     }
