@@ -27,6 +27,19 @@ def _world(group=None):
     return dist.get_rank(group), dist.get_world_size(group)
 
 
+def _wire(t):
+    """The tensor as the process group sees it.  RCCL's torch binding moves 1-, 4- and 8-byte integers, halves, floats and
+    doubles but REFUSES 16-bit integers ("Input tensor data type is not supported for NCCL process group: Short",
+    found by tests/test_gpu_rccl_one_rank.py on the one-GPU box) -- and the disparity maps are CV_16S.  A contiguous
+    int16 / uint16 block therefore travels as its bytes: the same memory, no copy, the receiver's view writes straight
+    into the int16 tensor."""
+    if t.dtype in (torch.int16, torch.uint16):
+        if not t.is_contiguous():
+            raise ValueError("a 16-bit block must be contiguous to travel as bytes")
+        return t.view(torch.uint8)
+    return t
+
+
 def scatter_batch(full, n_total, item_shape, dtype, device, src=0, group=None):
     """Root holds `full` (n_total, *item_shape); every rank returns its own shard.
 
@@ -44,13 +57,13 @@ def scatter_batch(full, n_total, item_shape, dtype, device, src=0, group=None):
                 continue
             a, b = shard_range(n_total, peer, world)
             if b > a:
-                ops.append(dist.P2POp(dist.isend, full[a:b].contiguous(), peer, group))
+                ops.append(dist.P2POp(dist.isend, _wire(full[a:b].contiguous()), peer, group))
         for w in (dist.batch_isend_irecv(ops) if ops else []):
             w.wait()
         return full[start:stop]
     local = torch.empty((stop - start,) + tuple(item_shape), dtype=dtype, device=device)
     if stop > start:
-        for w in dist.batch_isend_irecv([dist.P2POp(dist.irecv, local, src, group)]):
+        for w in dist.batch_isend_irecv([dist.P2POp(dist.irecv, _wire(local), src, group)]):
             w.wait()
     return local
 
@@ -70,12 +83,12 @@ def gather_batch(local, n_total, dst=0, group=None):
                 continue
             a, b = shard_range(n_total, peer, world)
             if b > a:
-                ops.append(dist.P2POp(dist.irecv, full[a:b], peer, group))
+                ops.append(dist.P2POp(dist.irecv, _wire(full[a:b]), peer, group))
         for w in (dist.batch_isend_irecv(ops) if ops else []):
             w.wait()
         return full
     if local.shape[0] > 0:
-        for w in dist.batch_isend_irecv([dist.P2POp(dist.isend, local.contiguous(), dst, group)]):
+        for w in dist.batch_isend_irecv([dist.P2POp(dist.isend, _wire(local.contiguous()), dst, group)]):
             w.wait()
     return None
 
@@ -185,11 +198,11 @@ def pipelined_scatter_filter_gather(full, n_total, in_shapes, in_dtypes, out_sha
                     continue
                 lo, hi = sub_range(n_total, peer, world, s, n_sub)
                 if hi > lo:
-                    ops += [dist.P2POp(dist.isend, t[lo:hi], peer, group) for t in full]
+                    ops += [dist.P2POp(dist.isend, _wire(t[lo:hi]), peer, group) for t in full]
         else:
             lo, hi = sub_range(n_total, rank, world, s, n_sub)
             if hi > lo:
-                ops += [dist.P2POp(dist.irecv, t[lo - a:hi - a], src, group) for t in local_in]
+                ops += [dist.P2POp(dist.irecv, _wire(t[lo - a:hi - a]), src, group) for t in local_in]
         return post(ops)
 
     def post_gather(s):
@@ -202,11 +215,11 @@ def pipelined_scatter_filter_gather(full, n_total, in_shapes, in_dtypes, out_sha
                     continue
                 lo, hi = sub_range(n_total, peer, world, s, n_sub)
                 if hi > lo:
-                    ops.append(dist.P2POp(dist.irecv, full_out[lo:hi], peer, group))
+                    ops.append(dist.P2POp(dist.irecv, _wire(full_out[lo:hi]), peer, group))
         else:
             lo, hi = sub_range(n_total, rank, world, s, n_sub)
             if hi > lo:
-                ops.append(dist.P2POp(dist.isend, local_out[lo - a:hi - a], src, group))
+                ops.append(dist.P2POp(dist.isend, _wire(local_out[lo - a:hi - a]), src, group))
         return post(ops)
 
     dsync()

@@ -20,6 +20,19 @@ def test_shard_ranges_partition_the_batch():
             assert max(sizes) - min(sizes) <= 1
 
 
+def test_16_bit_blocks_travel_as_bytes():
+    t = torch.arange(24, dtype=torch.int16).reshape(2, 3, 4)
+    w = parallel._wire(t[1:])
+    assert w.dtype == torch.uint8 and w.shape == (1, 3, 8) and w.data_ptr() == t[1:].data_ptr()
+    w.zero_()
+    assert int(t[1:].abs().sum()) == 0 and int(t[0].sum()) == sum(range(12))
+    for dt in (torch.uint8, torch.float32, torch.int32):
+        x = torch.zeros(3, dtype=dt)
+        assert parallel._wire(x) is x
+    with pytest.raises(ValueError):
+        parallel._wire(t[:, :, ::2])
+
+
 def _free_port():
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
@@ -35,6 +48,9 @@ def _worker(rank, world, port, n_total, q):
     try:
         dev = torch.device("cpu")
         shape = (6, 10)
+        # RCCL's binding refuses 16-bit integers (tests/test_gpu_rccl_one_rank.py): nothing may be posted as one
+        make_op, posted = dist.P2POp, []
+        dist.P2POp = lambda op, tensor, *a, **k: (posted.append(tensor.dtype), make_op(op, tensor, *a, **k))[1]
         full = None
         if rank == 0:
             full = torch.arange(n_total * 60, dtype=torch.int16).reshape((n_total,) + shape)
@@ -53,7 +69,8 @@ def _worker(rank, world, port, n_total, q):
             ok_gather = gathered is None
         tmax = parallel.max_over_ranks(1.0 + rank, dev)
         tsum = parallel.sum_over_ranks(1.0 + rank, dev)
-        q.put((rank, ok_scatter, ok_gather, tmax, tsum))
+        ok_wire = all(d == torch.uint8 for d in posted) and (len(posted) > 0 or n_total < world)
+        q.put((rank, ok_scatter and ok_wire, ok_gather, tmax, tsum))
     finally:
         dist.destroy_process_group()
 
