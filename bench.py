@@ -638,6 +638,11 @@ def rccl_legs(parallel, torch, dist, rank, world, dev, coll_dev, n_total, pairs,
             full, ok_build = None, 0.0
     if parallel.min_over_ranks(ok_build, coll_dev) < 0.5:
         return {"skipped": "rank 0 could not build the whole batch"}
+    # the first point-to-point call between two ranks sets the connection up (xGMI channels, buffers): not transfer time
+    warm = parallel.scatter_batch(torch.zeros((world, 64), dtype=torch.uint8, device=dev) if rank == 0 else None,
+                                  world, (64,), torch.uint8, dev)
+    parallel.gather_batch(warm.contiguous(), world)
+    del warm
     sync(); dist.barrier()
     t0 = time.perf_counter()
     got = [parallel.scatter_batch(None if full is None else full[k], n_total, in_shapes[k], in_dtypes[k], dev)
