@@ -25,6 +25,7 @@ from .ximgproc import (  # noqa: F401
     createFastGlobalSmootherFilter,
     createRightMatcher,
     fastGlobalSmootherFilter,
+    releaseCachedMemory,
     getDisparityVis,
     readGT,
 )

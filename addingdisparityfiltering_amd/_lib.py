@@ -74,6 +74,7 @@ SYMBOLS = [
     ("adf_fgs_create", _i, [C.POINTER(_vp), _vp, _pd, _i, _i, _i, _d, _d, _d, _i, _i]),
     ("adf_fgs_create_device", _i, [C.POINTER(_vp), _vp, _pd, _i, _i, _i, _d, _d, _d, _i, _i, _vp]),
     ("adf_fgs_destroy", None, [_vp]),
+    ("adf_release_cached_memory", None, []),
     ("adf_fgs_get_device", _i, [_vp, C.POINTER(_i)]),
     ("adf_fgs_filter_host", _i, [_vp, _vp, _pd, _vp, _pd, _i, _i]),
     ("adf_fgs_filter_device", _i, [_vp, _vp, _pd, _vp, _pd, _i, _i, _vp]),
@@ -115,7 +116,12 @@ def lib():
                 "(python -c 'import __graft_entry__ as g; g.build()')" % LIB_PATH)
         L = C.CDLL(LIB_PATH)
         for name, res, args in SYMBOLS:
-            fn = getattr(L, name)
+            try:
+                fn = getattr(L, name)
+            except AttributeError:
+                if os.environ.get("ADF_WLS_LIB"):     # an A/B build of older sources may lack the newest entry points
+                    continue
+                raise
             fn.restype = res
             fn.argtypes = args
         _lib = L

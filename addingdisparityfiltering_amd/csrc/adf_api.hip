@@ -12,7 +12,10 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <memory>
+#include <mutex>
 #include <new>
+#include <thread>
 #include <vector>
 
 using namespace adf;
@@ -113,14 +116,73 @@ struct DevBuf {
 };
 
 // Weight LUTs (FGS.cpp:150-154, 663-675), built on the host with libm, one immutable device table per sigma seen
-// (up to LUT_CACHE of them).  Round 3: a table is never rewritten, so coming back to a sigma used before -- the common
-// way callers vary it -- is a pointer switch with no device work and no synchronisation (capturable into a hipGraph),
-// and a NEW sigma no longer drains the stream: its table goes into a fresh buffer no kernel in flight can be reading.
-// Only that first upload is a synchronous copy (the pageable staging vector dies at scope exit); a caller that captures
-// filter calls must have used every sigma it switches between once before the capture (include/adf_wls.h).
+// (up to LUT_CACHE of them per handle).  Round 3: a table is never rewritten, so coming back to a sigma used before --
+// the common way callers vary it -- is a pointer switch with no device work and no synchronisation (capturable into a
+// hipGraph), and a NEW sigma no longer drains the stream: its table goes into a fresh buffer no kernel in flight can be
+// reading.  Only that first upload is a synchronous copy; a caller that captures filter calls must have used every
+// sigma it switches between once before the capture (include/adf_wls.h).
+//
+// Tables are shared by every handle of the process on the same device (LutStore): the one-shot function
+// fastGlobalSmootherFilter (EF.hpp:413) and the reference's own perf test (perf_fgs_filter.cpp:70-76) create a filter
+// per call, and 3*256*256 libm calls cost ~1 ms on one core -- ten times the 720p filter call itself.  A table seen
+// before is a look-up; a new one is built by a few threads (each entry is the same scalar libm expression as before:
+// same bits).
+struct LutTable {
+    int device = 0; float sigma = 0; float* dev = nullptr;
+    LutTable() = default;
+    LutTable(const LutTable&) = delete;
+    LutTable& operator=(const LutTable&) = delete;
+    ~LutTable() { if (dev) { DeviceScope ds(device); hipFree(dev); } }
+};
+
+struct LutStore {
+    static constexpr size_t CAP = 16;
+    std::mutex m;
+    std::vector<std::shared_ptr<LutTable>> tables;               // most recently used last
+    static LutStore& get() { static LutStore* s = new LutStore; return *s; }   // (never destroyed: no HIP calls at exit)
+    std::shared_ptr<LutTable> find(int device, float sigma)
+    {
+        std::lock_guard<std::mutex> lk(m);
+        for (size_t k = 0; k < tables.size(); k++)
+            if (tables[k]->device == device && tables[k]->sigma == sigma) {
+                auto t = tables[k];
+                tables.erase(tables.begin() + (ptrdiff_t)k); tables.push_back(t);
+                return t;
+            }
+        return nullptr;
+    }
+    void add(const std::shared_ptr<LutTable>& t)
+    {
+        std::lock_guard<std::mutex> lk(m);
+        // (a table dropped here lives on while a handle still refers to it; with no handle left nothing can be reading it)
+        if (tables.size() >= CAP) tables.erase(tables.begin());
+        tables.push_back(t);
+    }
+    void clear() { std::lock_guard<std::mutex> lk(m); tables.clear(); }
+};
+
+static void lut_build_host(float s, float* host)
+{
+    auto span = [&](int a, int b) { for (int i = a; i < b; i++) host[i] = -expf(-sqrtf((float)i) / s); };
+    unsigned hw = std::thread::hardware_concurrency();
+    const int nt = (int)(hw >= 16 ? 8 : hw >= 4 ? hw / 2 : 1);
+    if (nt <= 1) { span(0, ADF_LUT_LEVELS); return; }
+    std::vector<std::thread> th;
+    const int per = (ADF_LUT_LEVELS + nt - 1) / nt;
+    bool ok = true;
+    int done = per;                                               // the caller's own share is [0, per)
+    for (int t = 1; t < nt && ok; t++) {
+        const int a = t * per, b = std::min(ADF_LUT_LEVELS, a + per);
+        try { th.emplace_back(span, a, b); done = b; } catch (...) { ok = false; }
+    }
+    span(0, per);
+    for (auto& t : th) t.join();
+    if (done < ADF_LUT_LEVELS) span(done, ADF_LUT_LEVELS);        // threads that could not be started
+}
+
 struct Lut {
     static constexpr int LUT_CACHE = 8;
-    struct Entry { float sigma; float* dev; unsigned long long used; };
+    struct Entry { std::shared_ptr<LutTable> t; unsigned long long used; };
     std::vector<Entry> tables;
     const float* cur = nullptr;
     unsigned long long tick = 0;
@@ -128,31 +190,104 @@ struct Lut {
     int ensure(float s, hipStream_t st)
     {
         for (auto& e : tables)
-            if (e.sigma == s) { e.used = ++tick; cur = e.dev; return ADF_OK; }
-        if ((int)tables.size() >= LUT_CACHE) {                 // evict the least recently used table: kernels of
+            if (e.t->sigma == s) { e.used = ++tick; cur = e.t->dev; return ADF_OK; }
+        if ((int)tables.size() >= LUT_CACHE) {                 // drop the least recently used table: kernels of
             size_t lru = 0;                                    // earlier calls on `st` may still read it
             for (size_t k = 1; k < tables.size(); k++) if (tables[k].used < tables[lru].used) lru = k;
             HIP_TRY(hipStreamSynchronize(st));
-            HIP_TRY(hipFree(tables[lru].dev));
             tables.erase(tables.begin() + (ptrdiff_t)lru);
         }
-        std::vector<float> host(ADF_LUT_LEVELS);
-        for (int i = 0; i < ADF_LUT_LEVELS; i++) host[i] = -expf(-sqrtf((float)i) / s);
-        float* d = nullptr;
-        HIP_TRY(hipMalloc(&d, sizeof(float) * ADF_LUT_LEVELS));
-        hipError_t e = hipMemcpy(d, host.data(), sizeof(float) * ADF_LUT_LEVELS, hipMemcpyHostToDevice);
-        if (e != hipSuccess) { hipFree(d); return fail(ADF_EHIP, "LUT upload failed: %s", hipGetErrorString(e)); }
-        tables.push_back(Entry{s, d, ++tick});
-        cur = d;
+        int device = 0;
+        HIP_TRY(hipGetDevice(&device));
+        std::shared_ptr<LutTable> t = LutStore::get().find(device, s);
+        if (!t) {
+            std::vector<float> host(ADF_LUT_LEVELS);
+            lut_build_host(s, host.data());
+            float* d = nullptr;
+            HIP_TRY(hipMalloc(&d, sizeof(float) * ADF_LUT_LEVELS));
+            hipError_t e = hipMemcpy(d, host.data(), sizeof(float) * ADF_LUT_LEVELS, hipMemcpyHostToDevice);
+            if (e != hipSuccess) { hipFree(d); return fail(ADF_EHIP, "LUT upload failed: %s", hipGetErrorString(e)); }
+            t = std::make_shared<LutTable>();
+            t->device = device; t->sigma = s; t->dev = d;
+            LutStore::get().add(t);
+        }
+        tables.push_back(Entry{t, ++tick});
+        cur = t->dev;
         return ADF_OK;
     }
-    void release() { for (auto& e : tables) hipFree(e.dev); tables.clear(); cur = nullptr; }
+    // (the caller has made sure no kernel still reads the tables: handle destruction synchronises first)
+    void release() { tables.clear(); cur = nullptr; }
+};
+
+// Device blocks of short-lived handles (adf_fgs: the planes and the staged image of ONE image), kept for the next
+// handle instead of going back to the driver: hipMalloc + hipFree of a 4K handle's 300 MB cost more than its filter
+// call, and hipFree waits for the whole device.  A block comes back with the event behind its last user; whoever takes
+// it makes its own stream wait for that event first, so nobody synchronises the host.
+struct BlockCache {
+    struct Ent { int device; void* p; size_t bytes; hipEvent_t ready; };
+    static constexpr size_t CAP_BYTES = (size_t)3 << 30;
+    static constexpr size_t CAP_ENTRIES = 8;
+    std::mutex m;
+    std::vector<Ent> ents;                                         // oldest first
+    size_t total = 0;
+    static BlockCache& get() { static BlockCache* c = new BlockCache; return *c; }
+    static void drop(const Ent& e)
+    {
+        DeviceScope ds(e.device);
+        if (e.ready) { hipEventSynchronize(e.ready); hipEventDestroy(e.ready); }
+        hipFree(e.p);
+    }
+    // a cached block of at least `need` bytes (and not wastefully larger), ordered into `st`; null if there is none
+    void* take(int device, size_t need, hipStream_t st, size_t* bytes)
+    {
+        Ent hit{};
+        {
+            std::lock_guard<std::mutex> lk(m);
+            size_t best = ents.size();
+            for (size_t k = 0; k < ents.size(); k++)
+                if (ents[k].device == device && ents[k].bytes >= need && ents[k].bytes <= need + need / 4 + ((size_t)1 << 20) &&
+                    (best == ents.size() || ents[k].bytes < ents[best].bytes))
+                    best = k;
+            if (best == ents.size()) return nullptr;
+            hit = ents[best];
+            ents.erase(ents.begin() + (ptrdiff_t)best);
+            total -= hit.bytes;
+        }
+        if (hit.ready) {
+            const hipError_t e = hipStreamWaitEvent(st, hit.ready, 0);
+            if (e != hipSuccess) hipEventSynchronize(hit.ready);
+            hipEventDestroy(hit.ready);
+        }
+        *bytes = hit.bytes;
+        return hit.p;
+    }
+    void give(int device, void* p, size_t bytes, hipEvent_t ready)
+    {
+        std::vector<Ent> out;
+        {
+            std::lock_guard<std::mutex> lk(m);
+            ents.push_back(Ent{device, p, bytes, ready});
+            total += bytes;
+            while (!ents.empty() && (total > CAP_BYTES || ents.size() > CAP_ENTRIES)) {
+                out.push_back(ents.front());
+                total -= ents.front().bytes;
+                ents.erase(ents.begin());
+            }
+        }
+        for (auto& e : out) drop(e);
+    }
+    void clear()
+    {
+        std::vector<Ent> out;
+        { std::lock_guard<std::mutex> lk(m); out.swap(ents); total = 0; }
+        for (auto& e : out) drop(e);
+    }
 };
 
 // Per-launch HIP-event timing (adf_wls_profile_*).  Events are pooled and reused.
-enum KClass { K_FILL = 0, K_WEIGHTS, K_DISC, K_LRC, K_PROLOGUE, K_PASS_H_FIRST, K_PASS_H, K_PASS_V, K_PASS_V_LAST, K_COUNT };
+enum KClass { K_FILL = 0, K_WEIGHTS, K_DISC, K_LRC, K_PROLOGUE, K_PASS_H_FIRST, K_PASS_H, K_PASS_V, K_PASS_V_LAST, K_RESIZE, K_COUNT };
 static const char* const kclass_names[K_COUNT] = {"fill_outside", "weights", "discontinuity", "lrc_confidence",
-                                                  "plain_prologue", "pass_h_first", "pass_h", "pass_v", "pass_v_last"};
+                                                  "plain_prologue", "pass_h_first", "pass_h", "pass_v", "pass_v_last", "resize"};
 struct Profiler {
     bool on = false;
     struct Rec { int cls; hipEvent_t a, b; double alg, moved; };
@@ -443,14 +578,20 @@ static size_t wls_pair_ws_bytes(const Geom& g, bool conf, bool wave, bool disc_m
     return planes * g.plane * sizeof(float) + (conf && disc_maps ? 2 * g.frame * sizeof(float) : 0);
 }
 
-// conf_given: h->conf already holds the view-sized confidence planes of all pairs (down-scaled path,
-// DF.cpp:274); the confidence kernels are skipped and dispR is not used.
+// What the down-scaled path queues where a same-size call runs its confidence kernels: the low-resolution confidence
+// map and the two resizes, for ALL pairs of the call, on the caller's stream -- i.e. beside the weight kernel, which
+// wls_filter_impl has forked to the side stream by then.
+struct ScaledStage;
+static int run_scaled_stage(const ScaledStage& s, hipStream_t st, Profiler* prof, int part);
+
+// conf_given: the down-scaled path (DF.cpp:274): the confidence kernels are skipped and dispR is not used; `scaled`
+// (may be null) fills h->conf with the view-sized confidence planes of all pairs and produces dispL itself.
 static int wls_filter_impl(adf_wls_t* h, int n_pairs,
                            const int16_t* dispL, ptrdiff_t sL, ptrdiff_t psL,
                            const uint8_t* view, ptrdiff_t sG, ptrdiff_t psG, int gch, int W, int H,
                            int16_t* out, ptrdiff_t sO, ptrdiff_t psO,
                            const int16_t* dispR, ptrdiff_t sR, ptrdiff_t psR,
-                           const adf_rect* roi_in, bool conf_given, hipStream_t st)
+                           const adf_rect* roi_in, bool conf_given, hipStream_t st, const ScaledStage* scaled = nullptr)
 {
     NEED_HANDLE(h);
     // DF.cpp:221-222
@@ -546,6 +687,7 @@ static int wls_filter_impl(adf_wls_t* h, int n_pairs,
             OutsideArgs oa{o, sO, psO, fill, nullptr, g};
             ProfScope ps(prof, K_FILL, 2.0 * (F - P), 2.0 * (F - P), st);
             HIP_TRY(launch_outside(oa, n, st));
+            if (scaled && first == 0 && (rc = run_scaled_stage(*scaled, st, prof, 1))) return rc;
         }
         WeightArgs wa{gv, sG, psG, gch, h->lut.cur, p.CH, p.CV, orient_h, orient_cv, g,
                       wave ? nullptr : p.B0};   // exact: B0 is free until the first pass writes its output there
@@ -568,10 +710,12 @@ static int wls_filter_impl(adf_wls_t* h, int n_pairs,
         // FIRST there: alone it takes 0.08 ms of a 64 x 4K step on the StereoBM factory's ROI, but queued behind the
         // weight kernel it starts when the confidence kernel's workgroups hold nearly every register of every CU and
         // crawls through 0.8 ms as the call's tail (round 3)
-        const bool outside_on_side = fork_weights && !conf_given && wave && h->disc_radius <= conf_left_max_radius();
+        // (down-scaled path: the resized confidence map covers the whole frame, only the output is filled)
+        const bool outside_on_side = fork_weights && wave && (conf_given || h->disc_radius <= conf_left_max_radius());
         if (outside_on_side) {
-            OutsideArgs oa{o, sO, psO, fill, (float*)h->conf.p + (size_t)first * g.cframe, g};
-            ProfScope ps(prof, K_FILL, 6.0 * (F - P), 6.0 * (F - P), wst);
+            OutsideArgs oa{o, sO, psO, fill, conf_given ? nullptr : (float*)h->conf.p + (size_t)first * g.cframe, g};
+            const double ob = (conf_given ? 2.0 : 6.0) * (F - P);
+            ProfScope ps(prof, K_FILL, ob, ob, wst);
             HIP_TRY(launch_outside(oa, n, wst));
         }
         if (!merged) {
@@ -592,12 +736,13 @@ static int wls_filter_impl(adf_wls_t* h, int n_pairs,
             da.roll_off = h->roll_off; da.W = W; da.frame = g.frame; da.only_view = -1;
             WavePassArgs fuse{};                                            // inputs of a fused first pass
             if (conf_given) {
-                // confidence already resized to the view (DF.cpp:274): only the prologue remains (DF.cpp:286-290)
-                OutsideArgs oa{o, sO, psO, fill, nullptr, g};
-                {
+                // confidence resized to the view (DF.cpp:274): only the prologue remains (DF.cpp:286-290)
+                if (!outside_on_side) {
+                    OutsideArgs oa{o, sO, psO, fill, nullptr, g};
                     ProfScope ps(prof, K_FILL, 2.0 * (F - P), 2.0 * (F - P), st);
                     HIP_TRY(launch_outside(oa, n, st));                    // DF.cpp:284
                 }
+                if (scaled && first == 0 && ((rc = run_scaled_stage(*scaled, st, prof, 0)) || (rc = run_scaled_stage(*scaled, st, prof, 1)))) return rc;
                 fuse.conf_in = confp; fuse.conf_frame = g.cframe; fuse.conf_pitch = g.cpitch; fuse.conf_x0 = g.cx0 + roi.x; fuse.conf_y0 = roi.y;
                 fuse.dl_in = dL; fuse.dl_stride = sL; fuse.dl_pair_stride = psL; fuse.dl_x0 = roi.x; fuse.dl_y0 = roi.y;
                 fuse.len = g.rw;
@@ -691,6 +836,73 @@ extern "C" int adf_wls_filter_device(adf_wls_t* h, int n_pairs,
                            false, (hipStream_t)stream);
 }
 
+struct ScaledStage {
+    adf_wls_t* h; int n_pairs;
+    const int16_t* dispL; ptrdiff_t sL, psL;
+    const int16_t* dispR; ptrdiff_t sR, psR;
+    int dW, dH, W, H;
+    adf_rect rlo; Geom ghi;
+    float resize_factor, x_ratio;
+    char* dhi; size_t dhi_bytes;
+    float *cl, *cr, *clo;
+    bool conf;
+};
+
+// part 0: the low-resolution confidence map; part 1: the two resizes.  Both are queued beside the weight kernel (after
+// its fork).  Measured at 64 x 4K views / 1080p maps: everything after the fork 13.8-14.1 / 13.8-14.0 ms per call (radius 2 / 5;
+// the band kernel crawls beside the weight kernel's small workgroups, 0.44 -> 0.9-1.7 ms, but the resizes then run
+// alone), part 0 before the fork 14.20 / 14.51 (two memory-bound kernels side by side gain nothing), no overlap at all
+// 14.49 / 14.69.
+static int run_scaled_stage(const ScaledStage& s, hipStream_t st, Profiler* prof, int part)
+{
+    adf_wls_t* h = s.h;
+    const int n_pairs = s.n_pairs, dW = s.dW, dH = s.dH, W = s.W, H = s.H;
+    const size_t lo = (size_t)dW * dH;
+    const adf_rect& rlo = s.rlo;
+    const double Plo = (double)rlo.width * rlo.height * n_pairs, Fhi = (double)W * H * n_pairs;
+    const bool band_map = s.conf && h->conf_band && conf_band_fits(plain_conf_layout(make_geom(dW, dH, rlo.x, rlo.y, rlo.width, rlo.height)), h->disc_radius);
+    if (s.conf && part == 0) {
+        const Geom glo = plain_conf_layout(make_geom(dW, dH, rlo.x, rlo.y, rlo.width, rlo.height));
+        const int rrx = dW - (rlo.x + rlo.width);                          // DF.cpp:202
+        DiscArgs da{};
+        da.disp[0] = s.dispL; da.stride[0] = s.sL; da.pair_stride[0] = s.psL; da.rx[0] = rlo.x; da.dst[0] = s.cl;
+        da.disp[1] = s.dispR; da.stride[1] = s.sR; da.pair_stride[1] = s.psR; da.rx[1] = rrx; da.dst[1] = s.cr;
+        da.ry = rlo.y; da.rw = rlo.width; da.rh = rlo.height; da.radius = h->disc_radius;
+        da.roll_off = h->roll_off / (s.resize_factor * s.resize_factor);    // DF.cpp:359
+        da.W = dW; da.frame = lo; da.only_view = -1;
+        const int thresh_lo = (int)(s.resize_factor * h->lrc_thresh);       // DF.cpp:318
+        if (band_map) {
+            // the one-sweep kernel at the maps' resolution: ROI pixels from the band kernel, zeros outside (DF.cpp:187-190)
+            ConfBandArgs ba{s.dispL, s.sL, s.psL, s.dispR, s.sR, s.psR, s.clo, glo, rrx, thresh_lo, h->disc_radius, da.roll_off, 0};
+            {
+                ProfScope ps(prof, K_LRC, 8.0 * Plo, 8.0 * Plo, st);
+                HIP_TRY(launch_conf_band(ba, n_pairs, st));                // DF.cpp:197-210
+            }
+            // (zeros outside the ROI: the resize's window)
+        } else {
+            {
+                ProfScope ps(prof, K_DISC, 4.0 * Plo, 12.0 * Plo, st);
+                HIP_TRY(launch_discontinuity(da, n_pairs, st));            // DF.cpp:204
+            }
+            LrcArgs la{s.dispL, s.sL, s.psL, s.dispR, s.sR, s.psR, s.cl, s.cr, s.clo, nullptr, 0, 0, 0, nullptr, nullptr, glo, rrx, thresh_lo, ORIENT_N};
+            ProfScope ps(prof, K_LRC, 4.0 * (double)lo * n_pairs, 4.0 * (double)lo * n_pairs + 12.0 * Plo, st);
+            HIP_TRY(launch_lrc_prologue(la, n_pairs, st));                 // DF.cpp:208-209
+        }
+    }
+    if (part == 0) return ADF_OK;
+    if (s.conf) {
+        ResizeArgs rc32{s.clo, (ptrdiff_t)dW * 4, (ptrdiff_t)(lo * 4), dW, dH, (float*)h->conf.p + s.ghi.cx0, (ptrdiff_t)s.ghi.cpitch * 4,
+                        (ptrdiff_t)(s.ghi.cframe * 4), W, H, (double)dW / W, (double)dH / H, 1.0f, 0};
+        if (band_map) { rc32.zero_outside = 1; rc32.vx0 = rlo.x; rc32.vy0 = rlo.y; rc32.vx1 = rlo.x + rlo.width; rc32.vy1 = rlo.y + rlo.height; }
+        ProfScope ps(prof, K_RESIZE, 4.0 * Fhi + 4.0 * (double)lo * n_pairs, 4.0 * Fhi + 4.0 * (double)lo * n_pairs, st);
+        HIP_TRY(launch_resize_linear(rc32, n_pairs, st));                  // DF.cpp:274
+    }
+    ResizeArgs r16{s.dispL, s.sL, s.psL, dW, dH, s.dhi, (ptrdiff_t)W * 2, (ptrdiff_t)s.dhi_bytes, W, H, (double)dW / W, (double)dH / H, s.x_ratio, 1};
+    ProfScope ps(prof, K_RESIZE, 2.0 * Fhi + 2.0 * (double)lo * n_pairs, 2.0 * Fhi + 2.0 * (double)lo * n_pairs, st);
+    HIP_TRY(launch_resize_linear(r16, n_pairs, st));                       // DF.cpp:243-244, 272-273
+    return ADF_OK;
+}
+
 // Down-scaled disparity path (DF.cpp:224-227, 239-247, 268-277): disparity maps of dW x dH, view and
 // output of W x H.  ROI is in disparity-map coordinates, like the reference's.
 extern "C" int adf_wls_filter_scaled_device(adf_wls_t* h, int n_pairs,
@@ -737,36 +949,13 @@ extern "C" int adf_wls_filter_scaled_device(adf_wls_t* h, int n_pairs,
     float* cr = cl + (size_t)n_pairs * lo;
     float* clo = cr + (size_t)n_pairs * lo;
     const Geom ghi = make_geom(W, H, rhi.x, rhi.y, rhi.width, rhi.height);   // the geometry wls_filter_impl will derive
-    if (conf) {
-        if ((rc = ensure_conf_planes(h, ghi, n_pairs, st))) return rc;
-        const Geom glo = plain_conf_layout(make_geom(dW, dH, rlo.x, rlo.y, rlo.width, rlo.height));
-        const int rrx = dW - (rlo.x + rlo.width);                          // DF.cpp:202
-        DiscArgs da{};
-        da.disp[0] = dispL; da.stride[0] = sL; da.pair_stride[0] = psL; da.rx[0] = rlo.x; da.dst[0] = cl;
-        da.disp[1] = dispR; da.stride[1] = sR; da.pair_stride[1] = psR; da.rx[1] = rrx; da.dst[1] = cr;
-        da.ry = rlo.y; da.rw = rlo.width; da.rh = rlo.height; da.radius = h->disc_radius;
-        da.roll_off = h->roll_off / (resize_factor * resize_factor);        // DF.cpp:359
-        da.W = dW; da.frame = lo; da.only_view = -1;
-        const int thresh_lo = (int)(resize_factor * h->lrc_thresh);         // DF.cpp:318
-        if (h->conf_band && conf_band_fits(glo, h->disc_radius)) {
-            // the one-sweep kernel at the maps' resolution: ROI pixels from the band kernel, zeros outside (DF.cpp:187-190)
-            ConfBandArgs ba{dispL, sL, psL, dispR, sR, psR, clo, glo, rrx, thresh_lo, h->disc_radius, da.roll_off, 0};
-            HIP_TRY(launch_conf_band(ba, n_pairs, st));                    // DF.cpp:197-210
-            OutsideArgs oa{nullptr, 0, 0, 0, clo, glo};
-            HIP_TRY(launch_outside(oa, n_pairs, st));
-        } else {
-            HIP_TRY(launch_discontinuity(da, n_pairs, st));                // DF.cpp:204
-            LrcArgs la{dispL, sL, psL, dispR, sR, psR, cl, cr, clo, nullptr, 0, 0, 0, nullptr, nullptr, glo, rrx, thresh_lo, ORIENT_N};
-            HIP_TRY(launch_lrc_prologue(la, n_pairs, st));                 // DF.cpp:208-209
-        }
-        ResizeArgs rc32{clo, (ptrdiff_t)dW * 4, (ptrdiff_t)(lo * 4), dW, dH, (float*)h->conf.p + ghi.cx0, (ptrdiff_t)ghi.cpitch * 4,
-                        (ptrdiff_t)(ghi.cframe * 4), W, H, (double)dW / W, (double)dH / H, 1.0f, 0};
-        HIP_TRY(launch_resize_linear(rc32, n_pairs, st));                  // DF.cpp:274
-    }
-    ResizeArgs r16{dispL, sL, psL, dW, dH, dhi, (ptrdiff_t)W * 2, (ptrdiff_t)dhi_bytes, W, H, (double)dW / W, (double)dH / H, x_ratio, 1};
-    HIP_TRY(launch_resize_linear(r16, n_pairs, st));                       // DF.cpp:243-244, 272-273
+    if (conf && (rc = ensure_conf_planes(h, ghi, n_pairs, st))) return rc;
+    ScaledStage stage{h, n_pairs, dispL, sL, psL, dispR, sR, psR, dW, dH, W, H, rlo, ghi, resize_factor, x_ratio,
+                      dhi, dhi_bytes, cl, cr, clo, conf};
+    // (without confidence the stage is the disparity resize alone; either way wls_filter_impl queues it after it has
+    // forked the weight kernel, which needs the view only)
     rc = wls_filter_impl(h, n_pairs, (const int16_t*)dhi, (ptrdiff_t)W * 2, (ptrdiff_t)dhi_bytes, view, sG, psG, gch, W, H,
-                         out, sO, psO, nullptr, 0, 0, &rhi, conf, st);
+                         out, sO, psO, nullptr, 0, 0, &rhi, conf, st, &stage);
     h->roi = rlo;                                                          // getROI(): valid_disp_ROI (DF.cpp:139)
     return rc;
 }
@@ -895,12 +1084,31 @@ struct adf_fgs {
     float lambda = 0, sigma = 0, atten = 0.25f; int num_iter = 3; int solver = ADF_SOLVER_EXACT;
     Geom g{};
     Lut lut;
-    DevBuf planes; // CH CV D F0 A0 B0
-    DevBuf io;     // src / dst image staging
-    // device-guide create: the guide is staged in `io` and the weight kernel is queued on the creator's stream; filter
-    // calls (any stream) overwrite `io` with their source, so they first wait for this event (recorded behind the kernel)
-    hipEvent_t weights_done = nullptr;
+    // one device block (BlockCache): the planes CH CV D F0 A0 B0, then the src / dst image staging
+    void* block = nullptr; size_t block_bytes = 0;
+    DevBuf planes, io;            // views into `block` (never released on their own)
+    // Recorded behind the last thing the handle queued, on whatever stream that was.  Every call first makes its stream
+    // wait for it: a filter call overwrites `io` (where a device-guide create staged the guide for its weight kernel,
+    // and where the previous call's result may still be copied out on another stream).  At destruction the block goes
+    // to the cache together with this event.
+    hipEvent_t busy = nullptr;
+    bool in_capture = false;      // a call was captured into a graph: the event is no ordinary event any more
 };
+
+static int fgs_begin(adf_fgs* f, hipStream_t st)
+{
+    if (f->busy && !f->in_capture) HIP_TRY(hipStreamWaitEvent(st, f->busy, 0));
+    return ADF_OK;
+}
+
+static int fgs_end(adf_fgs* f, hipStream_t st)
+{
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(st, &cs) != hipSuccess) { (void)hipGetLastError(); cs = hipStreamCaptureStatusNone; }
+    if (cs != hipStreamCaptureStatusNone) { f->in_capture = true; return ADF_OK; }
+    if (f->busy && !f->in_capture) HIP_TRY(hipEventRecord(f->busy, st));
+    return ADF_OK;
+}
 
 // guide_on_device: `guide` is a HIP device pointer (copied into the handle on `st`, no host round trip).
 static int fgs_create_impl(adf_fgs_t** out, const uint8_t* guide, ptrdiff_t gstride, int gch, int w, int hgt,
@@ -926,11 +1134,30 @@ static int fgs_create_impl(adf_fgs_t** out, const uint8_t* guide, ptrdiff_t gstr
     f->g = make_geom(w, hgt, 0, 0, w, hgt);
     f->solver = (solver == ADF_SOLVER_WAVE && wave_fits(f->g)) ? ADF_SOLVER_WAVE : ADF_SOLVER_EXACT;
     int rc = f->lut.ensure(f->sigma, st);
-    if (!rc) rc = f->planes.reserve(6 * f->g.plane * sizeof(float), st);
-    const size_t gbytes = (size_t)w * hgt * gch;
-    if (!rc) rc = f->io.reserve(gbytes > (size_t)w * hgt * 16 ? gbytes : (size_t)w * hgt * 16, st);
     if (rc) { adf_fgs_destroy(f); return rc; }
-    hipError_t e = guide_on_device
+    const size_t gbytes = (size_t)w * hgt * gch;
+    const size_t planes_bytes = (6 * f->g.plane * sizeof(float) + 255) / 256 * 256;
+    const size_t io_bytes = ((gbytes > (size_t)w * hgt * 16 ? gbytes : (size_t)w * hgt * 16) + 255) / 256 * 256;
+    hipError_t e = hipSuccess;
+    f->block = BlockCache::get().take(f->device, planes_bytes + io_bytes, st, &f->block_bytes);
+    if (!f->block) {
+        e = hipMalloc(&f->block, planes_bytes + io_bytes);
+        if (e != hipSuccess) {
+            BlockCache::get().clear();                               // the cache may be what fills the memory
+            e = hipMalloc(&f->block, planes_bytes + io_bytes);
+        }
+        if (e != hipSuccess) {
+            f->block = nullptr; adf_fgs_destroy(f);
+            return fail(e == hipErrorOutOfMemory ? ADF_ENOMEM : ADF_EHIP, "adf_fgs_create: %s", hipGetErrorString(e));
+        }
+        f->block_bytes = planes_bytes + io_bytes;
+    }
+    f->planes.p = f->block; f->planes.bytes = planes_bytes;
+    f->io.p = (char*)f->block + planes_bytes; f->io.bytes = io_bytes;
+    // deterministic padding lanes: the sweeps read (and discard) pitch padding
+    e = hipMemsetAsync(f->block, 0, planes_bytes + io_bytes, st);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&f->busy, hipEventDisableTiming);
+    if (e == hipSuccess) e = guide_on_device
         ? hipMemcpy2DAsync(f->io.p, (size_t)w * gch, guide, gstride, (size_t)w * gch, hgt, hipMemcpyDeviceToDevice, st)
         : hipMemcpy2D(f->io.p, (size_t)w * gch, guide, gstride, (size_t)w * gch, hgt, hipMemcpyHostToDevice);
     if (e == hipSuccess) {
@@ -945,11 +1172,10 @@ static int fgs_create_impl(adf_fgs_t** out, const uint8_t* guide, ptrdiff_t gstr
     // device guide: they are queued on `st`; an event behind them orders every later filter call -- whatever stream it
     // is on -- after the kernel that still reads the staged guide
     if (e == hipSuccess && !guide_on_device) e = hipStreamSynchronize(st);
-    if (e == hipSuccess && guide_on_device) {
-        e = hipEventCreateWithFlags(&f->weights_done, hipEventDisableTiming);
-        if (e == hipSuccess) e = hipEventRecord(f->weights_done, st);
-    }
-    if (e != hipSuccess) { adf_fgs_destroy(f); return fail(ADF_EHIP, "adf_fgs_create: %s", hipGetErrorString(e)); }
+    // (a failed create may have queued work on `st` that the event was never recorded behind: drain it before the block
+    // goes back to the cache)
+    if (e != hipSuccess) { hipStreamSynchronize(st); adf_fgs_destroy(f); return fail(ADF_EHIP, "adf_fgs_create: %s", hipGetErrorString(e)); }
+    if ((rc = fgs_end(f, st))) { hipStreamSynchronize(st); adf_fgs_destroy(f); return rc; }
     *out = f;
     return ADF_OK;
 }
@@ -967,14 +1193,29 @@ extern "C" int adf_fgs_create_device(adf_fgs_t** out, const uint8_t* guide, ptrd
                            (hipStream_t)stream);
 }
 
+extern "C" void adf_release_cached_memory(void)
+{
+    BlockCache::get().clear();
+    LutStore::get().clear();
+}
+
 extern "C" int adf_fgs_get_device(const adf_fgs_t* f, int* device) { NEED_HANDLE(f); if (device) *device = f->device; return ADF_OK; }
 
 extern "C" void adf_fgs_destroy(adf_fgs_t* f)
 {
     if (!f) return;
     DeviceScope ds(f->device);
-    f->lut.release(); f->planes.release(); f->io.release();
-    if (f->weights_done) hipEventDestroy(f->weights_done);
+    if (f->block) {
+        if (f->busy && !f->in_capture) {
+            BlockCache::get().give(f->device, f->block, f->block_bytes, f->busy);    // (the event goes with the block)
+            f->busy = nullptr;
+        } else {
+            hipDeviceSynchronize();
+            hipFree(f->block);
+        }
+    }
+    if (f->busy) hipEventDestroy(f->busy);
+    f->lut.release();
     delete f;
 }
 
@@ -1032,12 +1273,12 @@ extern "C" int adf_fgs_filter_host(adf_fgs_t* f, const void* src, ptrdiff_t sstr
     if (rc) return rc;
     DeviceScope ds(f->device);
     hipStream_t st = nullptr;
-    if (f->weights_done) HIP_TRY(hipStreamWaitEvent(st, f->weights_done, 0));
+    if ((rc = fgs_begin(f, st))) return rc;
     HIP_TRY(hipMemcpy2DAsync(f->io.p, rowb, src, sstride, rowb, f->h, hipMemcpyHostToDevice, st));
     if ((rc = fgs_filter_staged(f, depth, channels, rowb, st))) return rc;
     HIP_TRY(hipMemcpy2DAsync(dst, dstride, f->io.p, rowb, rowb, f->h, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
-    return ADF_OK;
+    return fgs_end(f, st);
 }
 
 extern "C" int adf_fgs_filter_device(adf_fgs_t* f, const void* src, ptrdiff_t sstride, void* dst, ptrdiff_t dstride,
@@ -1049,9 +1290,9 @@ extern "C" int adf_fgs_filter_device(adf_fgs_t* f, const void* src, ptrdiff_t ss
     if (rc) return rc;
     DeviceScope ds(f->device);
     hipStream_t st = (hipStream_t)stream;
-    if (f->weights_done) HIP_TRY(hipStreamWaitEvent(st, f->weights_done, 0));
+    if ((rc = fgs_begin(f, st))) return rc;
     HIP_TRY(hipMemcpy2DAsync(f->io.p, rowb, src, sstride, rowb, f->h, hipMemcpyDeviceToDevice, st));
     if ((rc = fgs_filter_staged(f, depth, channels, rowb, st))) return rc;
     HIP_TRY(hipMemcpy2DAsync(dst, dstride, f->io.p, rowb, rowb, f->h, hipMemcpyDeviceToDevice, st));
-    return ADF_OK;
+    return fgs_end(f, st);
 }

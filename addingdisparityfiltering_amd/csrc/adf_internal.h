@@ -126,6 +126,7 @@ struct ResizeArgs {
     void* dst; ptrdiff_t dstride, dpair; int dw, dh;
     double scale_x, scale_y;                               // sw/dw, sh/dh
     float post_scale; int is16;
+    int zero_outside = 0, vx0 = 0, vy0 = 0, vx1 = 0, vy1 = 0; // source elements outside [vx0,vx1) x [vy0,vy1) read as zero
 };
 
 struct WeightArgs {

@@ -659,6 +659,12 @@ def fastGlobalSmootherFilter(guide, src, lambda_, sigma_color, lambda_attenuatio
     return createFastGlobalSmootherFilter(guide, lambda_, sigma_color, lambda_attenuation, num_iter, solver).filter(src, dst)
 
 
+def releaseCachedMemory():
+    """Returns the device blocks of destroyed filters and the weight tables the library keeps for the next filter
+    (include/adf_wls.h: adf_release_cached_memory) to the driver."""
+    _lib.lib().adf_release_cached_memory()
+
+
 # ---------------------------------------------------------------------------------------------
 # Evaluation utilities (DF.hpp:163-204, DF.cpp:460-556)
 # ---------------------------------------------------------------------------------------------

@@ -219,6 +219,13 @@ int adf_fgs_create_device(adf_fgs_t** out, const uint8_t* guide, ptrdiff_t guide
                           int w, int h, double lambda, double sigma_color, double lambda_attenuation,
                           int num_iter, int solver, void* stream);
 void adf_fgs_destroy(adf_fgs_t* h);
+/* Filters made and destroyed per call -- the one-shot fastGlobalSmootherFilter (EF.hpp:413, FGS.cpp:687-691), the
+ * reference's own perf test (perf/perf_fgs_filter.cpp:70-76) -- would pay hipMalloc + hipFree (which waits for the whole
+ * device) and 3*256*256 libm calls for the weight table on every call.  The library therefore keeps a destroyed
+ * filter's device block (at most 8 blocks / 3 GB per process, handed to the next filter behind the event of its last
+ * user: no host synchronisation) and the weight tables by (device, sigma) (16 of them).  This returns all of it to the
+ * driver; it waits for the blocks' last users. */
+void adf_release_cached_memory(void);
 int adf_fgs_get_device(const adf_fgs_t* h, int* device);
 
 /* FastGlobalSmootherFilter::filter(src, dst) (EF.hpp:370, FGS.cpp:182-233).

@@ -1,0 +1,84 @@
+"""Filters made and destroyed per call (EF.hpp:413 fastGlobalSmootherFilter; perf_fgs_filter.cpp:70-76): the library hands a
+destroyed filter's device block to the next one behind an event and shares weight tables by sigma (adf_api.hip:
+BlockCache, LutStore).  Results must not depend on any of that."""
+import numpy as np
+import pytest
+
+
+def _case(rng, w, h, gch, depth, cn):
+    guide = rng.integers(0, 256, (h, w, gch) if gch > 1 else (h, w), dtype=np.uint8)
+    shape = (h, w, cn) if cn > 1 else (h, w)
+    if depth == np.float32:
+        src = (rng.random(shape, dtype=np.float32) * 255).astype(np.float32)
+    else:
+        src = rng.integers(0, 256, shape).astype(depth)
+    return guide, src
+
+
+@pytest.mark.gpu
+def test_one_shot_calls_equal_the_oracle_through_block_reuse(adf, oracle):
+    """Same size again and again (every create after the first takes the previous filter's block), then other sizes,
+    fresh lambda / sigma every call as the reference's perf test draws them: exact solver bit for bit."""
+    rng = np.random.default_rng(11)
+    sizes = [(160, 96)] * 4 + [(131, 77), (160, 96), (320, 48), (131, 77)]
+    for k, (w, h) in enumerate(sizes):
+        gch, cn = (1, 3)[k % 2], (1, 3)[(k // 2) % 2]
+        depth = (np.uint8, np.int16, np.float32)[k % 3]
+        guide, src = _case(rng, w, h, gch, depth, cn)
+        lam, sig = float(rng.uniform(500.0, 10000.0)), float(rng.uniform(1.0, 100.0))
+        got = adf.fastGlobalSmootherFilter(guide, src, lam, sig, solver=adf.SOLVER_EXACT)
+        exp = oracle.fgs_filter(guide, src, lam, sig)
+        assert np.array_equal(got, exp), (k, w, h, gch, cn, depth)
+
+
+@pytest.mark.gpu
+def test_block_handed_over_between_streams(adf):
+    """Filter A works on stream 1 and is destroyed while its kernels are queued; filter B is created on stream 2 and gets
+    A's block: B's clearing of the block must wait for A's last copy-out (the event that travels with the block)."""
+    import torch
+
+    dev = torch.device("cuda", 0)
+    rng = np.random.default_rng(5)
+    w, h = 1280, 720
+    s1, s2 = torch.cuda.Stream(dev), torch.cuda.Stream(dev)
+    cases = []
+    for k in range(6):
+        guide, src = _case(rng, w, h, 3, np.float32, 3)
+        cases.append((torch.from_numpy(guide).to(dev), torch.from_numpy(src).to(dev), 3000.0 + 500 * k, 5.0 + k))
+    # reference results: one filter at a time, synchronised
+    expect = []
+    for g, s, lam, sig in cases:
+        f = adf.createFastGlobalSmootherFilter(g, lam, sig)
+        expect.append(f.filter(s).clone())
+        torch.cuda.synchronize()
+        del f
+    adf.releaseCachedMemory()
+    torch.cuda.synchronize()
+    outs = []
+    for k, (g, s, lam, sig) in enumerate(cases):
+        with torch.cuda.stream(s1 if k % 2 == 0 else s2):
+            f = adf.createFastGlobalSmootherFilter(g, lam, sig)
+            outs.append(f.filter(s))
+            del f                                   # destroyed with its work still queued
+    torch.cuda.synchronize()
+    for k in range(len(cases)):
+        assert torch.equal(outs[k], expect[k]), k
+
+
+@pytest.mark.gpu
+def test_more_sigmas_than_shared_tables_and_release(adf, oracle):
+    rng = np.random.default_rng(3)
+    guide, src = _case(rng, 96, 64, 3, np.uint8, 1)
+    sigmas = [1.0 + 0.75 * k for k in range(20)]          # more than the store keeps
+    first = {}
+    for sig in sigmas + sigmas[:4]:
+        got = adf.fastGlobalSmootherFilter(guide, src, 4000.0, sig, solver=adf.SOLVER_EXACT)
+        if sig in first:
+            assert np.array_equal(got, first[sig])
+        else:
+            first[sig] = got
+            if len(first) in (1, 10, 20):
+                assert np.array_equal(got, oracle.fgs_filter(guide, src, 4000.0, sig))
+    adf.releaseCachedMemory()
+    got = adf.fastGlobalSmootherFilter(guide, src, 4000.0, sigmas[0], solver=adf.SOLVER_EXACT)
+    assert np.array_equal(got, first[sigmas[0]])

@@ -96,3 +96,36 @@ def test_downscaled_batch_device_path(adf, oracle):
         d = np.abs(got[k].astype(np.int64) - exp)
         assert d.max() <= 1 and d.mean() <= 1 / 256
         assert np.array_equal(confs[k], exp_conf)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("sizes", [
+    ((320, 240), (224, 168)),      # 0.7: consecutive rows share source rows, taps fetched one by one
+    ((320, 240), (288, 216)),      # 0.9: every destination row brings its own two rows
+    ((320, 240), (400, 300)),      # maps LARGER than the view (a reduction)
+    ((320, 240), (160, 216)),      # 0.5 across, 0.9 down
+    ((320, 240), (288, 120)),      # 0.9 across, 0.5 down
+    ((321, 243), (107, 81)),       # a third, odd sizes (partial last vector, unaligned rows)
+    ((1283, 97), (640, 48)),       # wide and flat: more than one block across
+    ((64, 48), (24, 16)),          # tiny maps
+])
+def test_scaled_path_other_ratios(adf, oracle, sizes):
+    """The resize kernels pick their code path by the scale factors (resize_kernels.hip): one test per path and for the
+    mixed cases, confidence map bit-exact, exact solver bit-exact, wave solver within its tolerance."""
+    (w, h), (mw, mh) = sizes
+    view = synthetic.make_artificial_example(w, h, 3, seed=w + mh)[0]
+    _, dl, dr, roi = synthetic.make_artificial_example(mw, mh, 1, seed=mw + h)
+    roi = (min(roi[0], mw // 4), 0, mw - min(roi[0], mw // 4), mh)
+    p = oracle.default_params(sigma_color=1.5, threads=8, use_confidence=1)
+    exp, exp_conf = oracle.wls_filter_scaled(dl, view, dr, roi, p)
+    f = adf.createDisparityWLSFilterGeneric(True)
+    f.setSolver(adf.SOLVER_EXACT)
+    f.setSigmaColor(1.5)
+    got = f.filter(dl, view, None, dr, roi)
+    assert got.shape == (h, w)
+    assert np.array_equal(f.getConfidenceMap(), exp_conf)
+    assert np.array_equal(got, exp)
+    f.setSolver(adf.SOLVER_WAVE)
+    got2 = f.filter(dl, view, None, dr, roi)
+    d = np.abs(got2.astype(np.int64) - exp)
+    assert d.max() <= 1 and d.mean() <= 1 / 256
