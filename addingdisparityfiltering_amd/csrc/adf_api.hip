@@ -164,20 +164,36 @@ struct LutStore {
 static void lut_build_host(float s, float* host)
 {
     auto span = [&](int a, int b) { for (int i = a; i < b; i++) host[i] = -expf(-sqrtf((float)i) / s); };
+    // Where the argument is at or below -110 the float exponential is +0 -- exp(-110) = 1.7e-48 lies 400 times below half
+    // the smallest denormal, so every libm returns zero there, and the entry is -0.0f.  With the filter's usual sigma
+    // (1..2) that is nine tenths of the table: those entries are stored, not computed.  The argument falls
+    // monotonically with i (sqrtf and the division are monotone), so the first such index bounds the computed part.
+    int n = ADF_LUT_LEVELS;
+    if (s > 0.0f) {
+        const double lim = 110.0 * (double)s;
+        if (lim * lim * 1.001 + 2.0 < (double)ADF_LUT_LEVELS) {
+            int i0 = (int)(lim * lim * 1.001) + 2;
+            while (i0 < ADF_LUT_LEVELS && !(-sqrtf((float)i0) / s <= -110.0f)) i0++;   // (a check, not a search: the margin covers it)
+            n = i0;
+        }
+    }
+    for (int i = n; i < ADF_LUT_LEVELS; i++) host[i] = -0.0f;
     unsigned hw = std::thread::hardware_concurrency();
-    const int nt = (int)(hw >= 16 ? 8 : hw >= 4 ? hw / 2 : 1);
-    if (nt <= 1) { span(0, ADF_LUT_LEVELS); return; }
+    int nt = (int)(hw >= 16 ? 8 : hw >= 4 ? hw / 2 : 1);
+    if (n < 32768) nt = 1;                                        // a thread costs more to start than such a share to compute
+    if (nt <= 1) { span(0, n); return; }
     std::vector<std::thread> th;
-    const int per = (ADF_LUT_LEVELS + nt - 1) / nt;
+    const int per = (n + nt - 1) / nt;
     bool ok = true;
-    int done = per;                                               // the caller's own share is [0, per)
+    int done = std::min(per, n);                                  // the caller's own share is [0, per)
     for (int t = 1; t < nt && ok; t++) {
-        const int a = t * per, b = std::min(ADF_LUT_LEVELS, a + per);
+        const int a = t * per, b = std::min(n, a + per);
+        if (a >= b) break;
         try { th.emplace_back(span, a, b); done = b; } catch (...) { ok = false; }
     }
-    span(0, per);
+    span(0, std::min(per, n));
     for (auto& t : th) t.join();
-    if (done < ADF_LUT_LEVELS) span(done, ADF_LUT_LEVELS);        // threads that could not be started
+    if (done < n) span(done, n);                                  // threads that could not be started
 }
 
 struct Lut {
@@ -1219,10 +1235,11 @@ extern "C" void adf_fgs_destroy(adf_fgs_t* f)
     delete f;
 }
 
-// FastGlobalSmootherFilter::filter on an image staged in f->io (FGS.cpp:200-221: channels one by one).
-static int fgs_filter_staged(adf_fgs* f, int depth, int channels, size_t rowb, hipStream_t st)
+// FastGlobalSmootherFilter::filter (FGS.cpp:200-221: channels one by one) from the device image `src` into the device
+// image `dst` -- the same buffer (the host path's staging area; a caller filtering in place) or two that do not overlap.
+static int fgs_filter_run(adf_fgs* f, int depth, int channels, const void* src, ptrdiff_t sstride, void* dst, ptrdiff_t dstride,
+                          hipStream_t st)
 {
-    char* img = (char*)f->io.p;
     float* base = (float*)f->planes.p;
     const Geom& g = f->g;
     SolvePlanes p{};
@@ -1235,13 +1252,13 @@ static int fgs_filter_staged(adf_fgs* f, int depth, int channels, size_t rowb, h
         // solver takes them two at a time as the two right-hand sides of one factorisation (its pair plane
         // spans A0 and B0, which are adjacent) -- the same arithmetic per channel, half the passes.
         const int nr = (wave && c + 1 < channels) ? 2 : 1;
-        PlainPrologueArgs pa{img, (ptrdiff_t)rowb, 0, depth, channels, c, p.A0, g,
+        PlainPrologueArgs pa{src, sstride, 0, depth, channels, c, p.A0, g,
                              wave ? (nr == 2 ? ORIENT_PAIR : ORIENT_N) : ORIENT_T};
         pa.pair2 = nr == 2; pa.c2 = c + 1;
         HIP_TRY(launch_plain_prologue(pa, 1, st));
-        // the epilogue of channel c overwrites only channel c of the staged image, which later
+        // the epilogue of channel c overwrites only channel c of the image, which later
         // channels never read (they read their own channel), so filtering in place is safe
-        FinalOut fo{epi, img, (ptrdiff_t)rowb, 0, 0, 0, channels, c};
+        FinalOut fo{epi, dst, dstride, 0, 0, 0, channels, c};
         int rc = wave ? run_passes_wave(g, p, nr, f->lambda, f->atten, f->num_iter, fo, 1, st)
                       : run_passes_exact(g, p, 1, f->lambda, f->atten, f->num_iter, fo, 1, st);
         if (rc) return rc;
@@ -1275,7 +1292,7 @@ extern "C" int adf_fgs_filter_host(adf_fgs_t* f, const void* src, ptrdiff_t sstr
     hipStream_t st = nullptr;
     if ((rc = fgs_begin(f, st))) return rc;
     HIP_TRY(hipMemcpy2DAsync(f->io.p, rowb, src, sstride, rowb, f->h, hipMemcpyHostToDevice, st));
-    if ((rc = fgs_filter_staged(f, depth, channels, rowb, st))) return rc;
+    if ((rc = fgs_filter_run(f, depth, channels, f->io.p, (ptrdiff_t)rowb, f->io.p, (ptrdiff_t)rowb, st))) return rc;
     HIP_TRY(hipMemcpy2DAsync(dst, dstride, f->io.p, rowb, rowb, f->h, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
     return fgs_end(f, st);
@@ -1290,9 +1307,13 @@ extern "C" int adf_fgs_filter_device(adf_fgs_t* f, const void* src, ptrdiff_t ss
     if (rc) return rc;
     DeviceScope ds(f->device);
     hipStream_t st = (hipStream_t)stream;
+    // the images are filtered where they are (round 3: no staging copies): the first kernel of a channel reads `src`,
+    // the last one writes `dst`; dst == src (same pointer and stride) filters in place, anything else must not overlap
+    const char* s0 = (const char*)src; const char* d0 = (const char*)dst;
+    const size_t sspan = (size_t)sstride * (f->h - 1) + rowb, dspan = (size_t)dstride * (f->h - 1) + rowb;
+    if (!(src == dst && sstride == dstride) && s0 < d0 + dspan && d0 < s0 + sspan)
+        return fail(ADF_EBADARG, "dst must be src itself (same stride) or must not overlap it");
     if ((rc = fgs_begin(f, st))) return rc;
-    HIP_TRY(hipMemcpy2DAsync(f->io.p, rowb, src, sstride, rowb, f->h, hipMemcpyDeviceToDevice, st));
-    if ((rc = fgs_filter_staged(f, depth, channels, rowb, st))) return rc;
-    HIP_TRY(hipMemcpy2DAsync(dst, dstride, f->io.p, rowb, rowb, f->h, hipMemcpyDeviceToDevice, st));
+    if ((rc = fgs_filter_run(f, depth, channels, src, sstride, dst, dstride, st))) return rc;
     return fgs_end(f, st);
 }

@@ -82,3 +82,42 @@ def test_more_sigmas_than_shared_tables_and_release(adf, oracle):
     adf.releaseCachedMemory()
     got = adf.fastGlobalSmootherFilter(guide, src, 4000.0, sigmas[0], solver=adf.SOLVER_EXACT)
     assert np.array_equal(got, first[sigmas[0]])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("depth,cn", [(np.uint8, 1), (np.uint8, 3), (np.int16, 3), (np.float32, 4), (np.int16, 1)])
+def test_device_filter_where_the_images_are(adf, depth, cn):
+    """adf_fgs_filter_device reads `src` and writes `dst` directly (no staging copy): rows at any stride and alignment,
+    dst == src in place, overlapping buffers refused."""
+    import ctypes as C
+
+    import torch
+    from addingdisparityfiltering_amd import _lib
+
+    dev = torch.device("cuda", 0)
+    rng = np.random.default_rng(9)
+    w, h, pad_l, pad_r = 203, 57, 3, 6
+    guide, src = _case(rng, w, h, 3, depth, cn)
+    g = torch.from_numpy(guide).to(dev)
+    s = torch.from_numpy(src.reshape(h, w, cn)).to(dev)
+    f = adf.createFastGlobalSmootherFilter(g, 2500.0, 12.0)
+    want = f.filter(s.reshape(src.shape).contiguous()).reshape(h, w, cn).clone()      # dense tensors (the wrapper's path)
+    torch.cuda.synchronize()
+    big_s = torch.zeros((h, pad_l + w + pad_r, cn), dtype=s.dtype, device=dev)
+    big_d = torch.full((h, pad_r + w + pad_l, cn), 7, dtype=s.dtype, device=dev)
+    big_s[:, pad_l:pad_l + w] = s
+    vs, vd = big_s[:, pad_l:pad_l + w], big_d[:, pad_r:pad_r + w]
+    dcode = {np.uint8: _lib.DEPTH_8U, np.int16: _lib.DEPTH_16S, np.float32: _lib.DEPTH_32F}[depth]
+    esz = s.element_size()
+    st = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+    call = lambda a, sa, b, sb: _lib.lib().adf_fgs_filter_device(f._h, C.c_void_p(a.data_ptr()), sa, C.c_void_p(b.data_ptr()), sb, dcode, cn, st)
+    assert call(vs, big_s.shape[1] * cn * esz, vd, big_d.shape[1] * cn * esz) == 0
+    torch.cuda.synchronize()
+    assert torch.equal(vd, want)
+    assert int((big_d[:, :pad_r] != 7).sum()) == 0 and int((big_d[:, pad_r + w:] != 7).sum()) == 0   # padding untouched
+    assert torch.equal(vs, s)                                                                        # source untouched
+    assert call(vs, big_s.shape[1] * cn * esz, vs, big_s.shape[1] * cn * esz) == 0                   # in place
+    torch.cuda.synchronize()
+    assert torch.equal(vs, want)
+    # overlapping but not identical: refused
+    assert call(vs, big_s.shape[1] * cn * esz, big_s[:, pad_l + 1:pad_l + 1 + w], big_s.shape[1] * cn * esz) == _lib.ADF_EBADARG
