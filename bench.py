@@ -59,6 +59,9 @@ def parse_args(argv=None):
                     help="pairs of the extra views -> matcher -> filter leg (SURVEY 8f N4; N=1 only, 0 = skip)")
     ap.add_argument("--natural-pairs", type=int, default=8,
                     help="pairs of the extra leg on a natural-image guide (0 = skip; N = 1 only)")
+    ap.add_argument("--next-rows", type=int, default=16,
+                    help="pairs of the extra legs on SURVEY 8(f)'s rows N1 (down-scaled path) and N2 (generic FGS as the "
+                         "reference's perf test calls it); 0 = skip; N = 1 only")
     ap.add_argument("--dry-run", action="store_true",
                     help="launcher / rendezvous rehearsal without a GPU: gloo, no filter call, value 0 (tests)")
     ap.add_argument("--roi", default="config",
@@ -535,11 +538,99 @@ def worker(args):
         except Exception as e:                               # the extra leg must never cost the bench line
             line["natural_guide"] = {"error": str(e)}
 
+    if rank == 0 and world == 1 and not dry and args.next_rows > 0:
+        try:
+            line["next_rows"] = next_rows_leg(adf, torch, dev, synthetic, cfg, W, H, ch, base_seed, min(args.next_rows, pairs),
+                                              radius, not args.no_check)
+        except Exception as e:                               # the extra leg must never cost the bench line
+            line["next_rows"] = {"error": str(e)}
+
     if watchdog is not None:
         watchdog.cancel()
     emit()
     if world > 1:
         dist.destroy_process_group()
+
+
+def next_rows_leg(adf, torch, dev, synthetic, cfg, W, H, ch, seed, n, radius, check):
+    """SURVEY 8(f) rows N1 and N2 in the driver's own record (never part of `value`).
+    N1, the down-scaled path (DF.cpp:224-227, 239-247, 268-277; perf_disparity_wls_filter.cpp:76-83 and the sample's
+    default): `n` views of the config's size with HALF-size disparity maps, ROI halved.
+    N2, fastGlobalSmootherFilter as the reference's perf test calls it (perf_fgs_filter.cpp:55-76): 1280x720, guide 8UC3,
+    source 32FC3, a filter made AND one filter call per cycle with a fresh lambda / sigma every cycle.
+    One result of each is compared with the oracle."""
+    import time
+
+    import numpy as np
+
+    res = {}
+    # ---- N1 ----
+    dW, dH = W // 2, H // 2
+    view = synthetic.make_artificial_batch_torch(n, W, H, ch, seed + 7, cfg["rect_disparity"], dev)[0]
+    _, dl, dr = synthetic.make_artificial_batch_torch(n, dW, dH, ch, seed + 7, cfg["rect_disparity"] // 2, dev)
+    r = cfg["roi"]
+    roi = (r[0] // 2, r[1] // 2, r[2] // 2, r[3] // 2)
+    f = adf.createDisparityWLSFilterGeneric(True)
+    f.setLambda(8000.0); f.setSigmaColor(1.5); f.setDepthDiscontinuityRadius(radius)
+    out = None
+    for _ in range(2):
+        out = f.filter(dl, view, out, dr, roi)
+    torch.cuda.synchronize()
+    steps = 5
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(steps):
+        f.filter(dl, view, out, dr, roi)
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / steps
+    n1 = {"views": "%d x %dx%d, %d channel(s)" % (n, W, H, ch), "maps": "%dx%d" % (dW, dH), "roi_in_map_coordinates": list(roi),
+          "radius": radius, "ms_per_call": round(ms, 3), "Mpixels_per_s_view_pixels": round(n * W * H / ms / 1e3, 1)}
+    if check:
+        import oracle
+        p = oracle.default_params(threads=min(32, os.cpu_count() or 1), sigma_color=1.5, disc_radius=radius)
+        exp, exp_conf = oracle.wls_filter_scaled(dl[0].cpu().numpy(), view[0].cpu().numpy(), dr[0].cpu().numpy(), roi, p)
+        d = np.abs(out[0].cpu().numpy().astype(np.int32) - exp.astype(np.int32))
+        n1["checked"] = {"pair": 0, "confidence_bit_exact": bool(np.array_equal(f.getConfidenceMap(0).cpu().numpy(), exp_conf)),
+                         "disparity_max_abs_lsb": int(d.max()), "disparity_mean_abs_lsb": float(d.mean())}
+    res["down_scaled_path"] = n1
+    del f, view, dl, dr, out
+    # ---- N2 ----
+    w2, h2, cycles = 1280, 720, 10
+    rng = np.random.default_rng(seed)
+    guide = torch.from_numpy(rng.integers(0, 256, (h2, w2, 3), dtype=np.uint8)).to(dev)
+    src = torch.from_numpy((rng.random((h2, w2, 3), dtype=np.float32) * 255).astype(np.float32)).to(dev)
+    dst = torch.empty_like(src)
+    lam = [float(rng.uniform(500.0, 10000.0)) for _ in range(cycles + 2)]
+    sig = [float(rng.uniform(1.0, 100.0)) for _ in range(cycles + 2)]
+    for k in range(2):
+        adf.fastGlobalSmootherFilter(guide, src, lam[k], sig[k], dst=dst)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for k in range(cycles):
+        adf.fastGlobalSmootherFilter(guide, src, lam[2 + k], sig[2 + k], dst=dst)
+    torch.cuda.synchronize()
+    one_shot = (time.perf_counter() - t0) / cycles * 1e3
+    ff = adf.createFastGlobalSmootherFilter(guide, lam[-1], sig[-1])
+    ff.filter(src, dst)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for k in range(cycles):
+        ff.filter(src, dst)
+    torch.cuda.synchronize()
+    alone = (time.perf_counter() - t0) / cycles * 1e3
+    n2 = {"image": "%dx%d, guide 8UC3, source 32FC3" % (w2, h2), "cycles": cycles,
+          "create_plus_filter_ms_per_call": round(one_shot, 3), "filter_alone_ms_per_call": round(alone, 3),
+          "Mpixels_per_s_create_plus_filter": round(w2 * h2 / one_shot / 1e3, 1)}
+    if check:
+        import oracle
+        got = adf.fastGlobalSmootherFilter(guide, src, lam[-1], sig[-1], solver=adf.SOLVER_EXACT).cpu().numpy()
+        exp = oracle.fgs_filter(guide.cpu().numpy(), src.cpu().numpy(), lam[-1], sig[-1], threads=min(16, os.cpu_count() or 1))
+        n2["checked"] = {"exact_solver_bit_exact": bool(np.array_equal(got, exp)),
+                         "wave_solver_max_abs_diff": float(np.abs(dst.cpu().numpy() - exp).max())}
+    res["fgs_one_shot"] = n2
+    res["note"] = "SURVEY 8(f) rows N1 / N2 on the final kernels; not part of `value`"
+    return res
 
 
 def natural_guide_leg(adf, torch, dev, dl, dr, roi, radius, ch, n, solver, check):

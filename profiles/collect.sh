@@ -11,10 +11,10 @@ rm -rf ${tag}_stats ${tag}_pmc_fetch ${tag}_pmc_write
 # 1. the bench line itself (with the CPU baseline leg)
 python3 bench.py --solver $solver --steps 10 --warmup 3 > ${tag}_bench_n1.json 2> ${tag}_bench_n1.err
 # 2. per-kernel durations of the same command (shorter run, no CPU leg)
-rocprofv3 --kernel-trace --stats -d ${tag}_stats -o stats --output-format csv -- python3 bench.py --solver $solver --steps 5 --warmup 2 --cpu-seconds 0 --no-check --matcher-pairs 0 --natural-pairs 0 > ${tag}_stats.log 2>&1
+rocprofv3 --kernel-trace --stats -d ${tag}_stats -o stats --output-format csv -- python3 bench.py --solver $solver --steps 5 --warmup 2 --cpu-seconds 0 --no-check --matcher-pairs 0 --natural-pairs 0 --next-rows 0 > ${tag}_stats.log 2>&1
 # 3. HBM traffic: FETCH_SIZE and WRITE_SIZE in separate passes (8 pairs, one step, kernel trace only)
-rocprofv3 --kernel-trace --pmc FETCH_SIZE -d ${tag}_pmc_fetch -o pmc --output-format csv -- python3 bench.py --solver $solver --pairs 8 --steps 1 --warmup 0 --cpu-seconds 0 --no-check --matcher-pairs 0 --natural-pairs 0 > ${tag}_pmc_fetch.log 2>&1
-rocprofv3 --kernel-trace --pmc WRITE_SIZE -d ${tag}_pmc_write -o pmc --output-format csv -- python3 bench.py --solver $solver --pairs 8 --steps 1 --warmup 0 --cpu-seconds 0 --no-check --matcher-pairs 0 --natural-pairs 0 > ${tag}_pmc_write.log 2>&1
+rocprofv3 --kernel-trace --pmc FETCH_SIZE -d ${tag}_pmc_fetch -o pmc --output-format csv -- python3 bench.py --solver $solver --pairs 8 --steps 1 --warmup 0 --cpu-seconds 0 --no-check --matcher-pairs 0 --natural-pairs 0 --next-rows 0 > ${tag}_pmc_fetch.log 2>&1
+rocprofv3 --kernel-trace --pmc WRITE_SIZE -d ${tag}_pmc_write -o pmc --output-format csv -- python3 bench.py --solver $solver --pairs 8 --steps 1 --warmup 0 --cpu-seconds 0 --no-check --matcher-pairs 0 --natural-pairs 0 --next-rows 0 > ${tag}_pmc_write.log 2>&1
 # 4. the block matcher feeding the filter: its own kernel summary and timings
 if [ "$solver" = wave ]; then
   rm -rf gpurun_out/${round}_matcher_stats gpurun_out/${round}_sgbm_stats

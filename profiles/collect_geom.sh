@@ -12,8 +12,8 @@ python3 bench.py --steps 10 --warmup 3 > ${o}_wave_bench_n1.json 2> ${o}_wave_be
 python3 bench.py --steps 10 --warmup 3 --roi bm --cpu-seconds 0 --matcher-pairs 0 > ${o}_wave_bench_bmroi_n1.json 2> ${o}_wave_bench_bmroi_n1.err
 python3 bench.py --steps 10 --warmup 3 --radius 5 --cpu-seconds 0 --matcher-pairs 0 > ${o}_wave_bench_radius5_n1.json 2> ${o}_wave_bench_radius5_n1.err
 rm -rf ${o}_bmroi_stats ${o}_wave_stats
-rocprofv3 --kernel-trace --stats -d ${o}_bmroi_stats -o stats --output-format csv -- python3 bench.py --steps 5 --warmup 2 --roi bm --cpu-seconds 0 --no-check --matcher-pairs 0 --natural-pairs 0 > ${o}_bmroi_stats.log 2>&1
-rocprofv3 --kernel-trace --stats -d ${o}_wave_stats -o stats --output-format csv -- python3 bench.py --steps 5 --warmup 2 --cpu-seconds 0 --no-check --matcher-pairs 0 --natural-pairs 0 > ${o}_wave_stats.log 2>&1
+rocprofv3 --kernel-trace --stats -d ${o}_bmroi_stats -o stats --output-format csv -- python3 bench.py --steps 5 --warmup 2 --roi bm --cpu-seconds 0 --no-check --matcher-pairs 0 --natural-pairs 0 --next-rows 0 > ${o}_bmroi_stats.log 2>&1
+rocprofv3 --kernel-trace --stats -d ${o}_wave_stats -o stats --output-format csv -- python3 bench.py --steps 5 --warmup 2 --cpu-seconds 0 --no-check --matcher-pairs 0 --natural-pairs 0 --next-rows 0 > ${o}_wave_stats.log 2>&1
 find ${o}_bmroi_stats ${o}_wave_stats -name "*kernel_stats.csv"
 python3 - <<'PY'
 import json

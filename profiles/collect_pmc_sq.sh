@@ -5,7 +5,7 @@
 set -e
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 export ADF_NO_OVERLAP=1
-args="bench.py --pairs 8 --steps 1 --warmup 1 --cpu-seconds 0 --no-check --matcher-pairs 0 --natural-pairs 0"
+args="bench.py --pairs 8 --steps 1 --warmup 1 --cpu-seconds 0 --no-check --matcher-pairs 0 --natural-pairs 0 --next-rows 0"
 i=0
 for grp in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_LDS" \
            "SQ_INST_CYCLES_VMEM_WR SQ_INST_CYCLES_VMEM_RD SQ_VMEM_WR_TA_DATA_FIFO_FULL SQ_VMEM_TA_ADDR_FIFO_FULL SQ_VMEM_TA_CMD_FIFO_FULL SQ_INST_LEVEL_VMEM SQ_WAVES SQ_ACTIVE_INST_SCA"; do

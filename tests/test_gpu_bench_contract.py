@@ -44,3 +44,10 @@ def test_bench_line_contract():
     assert "error" not in ng, ng
     assert ng["Mpixels_per_s"] > 0 and 0 < ng["table_indices_beyond_lds_head"] < 0.2
     assert ng["checked"]["confidence_bit_exact"] is True and ng["checked"]["disparity_max_abs_lsb"] <= 1
+    nr = d["next_rows"]                              # extra legs: SURVEY 8(f) rows N1 / N2 (round 3)
+    assert "error" not in nr, nr
+    n1, n2 = nr["down_scaled_path"], nr["fgs_one_shot"]
+    assert n1["ms_per_call"] > 0 and n1["maps"] == "320x240"
+    assert n1["checked"]["confidence_bit_exact"] is True and n1["checked"]["disparity_max_abs_lsb"] <= 1
+    assert n2["create_plus_filter_ms_per_call"] >= n2["filter_alone_ms_per_call"] > 0
+    assert n2["checked"]["exact_solver_bit_exact"] is True and n2["checked"]["wave_solver_max_abs_diff"] < 0.05

@@ -6,6 +6,6 @@ for v in "$@"; do
   if [ "$v" != default ]; then export ADF_WLS_LIB=$GRAFT_REPO_ROOT/addingdisparityfiltering_amd/libadf_wls_$v.so; else unset ADF_WLS_LIB; fi
   echo "== variant $v"
   for rep in 1 2 3; do
-    ADF_NO_OVERLAP=1 python bench.py --cpu-seconds 0 --matcher-pairs 0 --natural-pairs 0 --no-check --steps 10 2>/dev/null | python -c "$show"
+    ADF_NO_OVERLAP=1 python bench.py --cpu-seconds 0 --matcher-pairs 0 --natural-pairs 0 --next-rows 0 --no-check --steps 10 2>/dev/null | python -c "$show"
   done
 done

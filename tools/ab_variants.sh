@@ -7,6 +7,6 @@ for rep in 1 2; do for v in "${vars[@]}"; do
   if [ "$v" != default ]; then export ADF_WLS_LIB=$GRAFT_REPO_ROOT/addingdisparityfiltering_amd/libadf_wls_$v.so; else unset ADF_WLS_LIB; fi
   for ov in 0 1; do
     echo "== variant $v ADF_NO_OVERLAP=$ov $*"
-    ADF_NO_OVERLAP=$ov python bench.py --cpu-seconds 0 --matcher-pairs 0 --natural-pairs 0 --no-check --steps 10 "$@" 2>/dev/null | python -c "$show"
+    ADF_NO_OVERLAP=$ov python bench.py --cpu-seconds 0 --matcher-pairs 0 --natural-pairs 0 --next-rows 0 --no-check --steps 10 "$@" 2>/dev/null | python -c "$show"
   done
 done; done
