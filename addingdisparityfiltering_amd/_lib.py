@@ -75,6 +75,7 @@ SYMBOLS = [
     ("adf_fgs_create_device", _i, [C.POINTER(_vp), _vp, _pd, _i, _i, _i, _d, _d, _d, _i, _i, _vp]),
     ("adf_fgs_destroy", None, [_vp]),
     ("adf_release_cached_memory", None, []),
+    ("adf_weight_table_host", _i, [C.c_float, _vp, _i]),
     ("adf_fgs_get_device", _i, [_vp, C.POINTER(_i)]),
     ("adf_fgs_filter_host", _i, [_vp, _vp, _pd, _vp, _pd, _i, _i]),
     ("adf_fgs_filter_device", _i, [_vp, _vp, _pd, _vp, _pd, _i, _i, _vp]),

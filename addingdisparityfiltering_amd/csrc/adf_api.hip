@@ -1209,6 +1209,14 @@ extern "C" int adf_fgs_create_device(adf_fgs_t** out, const uint8_t* guide, ptrd
                            (hipStream_t)stream);
 }
 
+extern "C" int adf_weight_table_host(float sigma_color, float* table, int levels)
+{
+    if (!table || levels != ADF_LUT_LEVELS) return fail(ADF_EBADARG, "table must hold %d floats", ADF_LUT_LEVELS);
+    if (!(sigma_color >= 0.0f)) return fail(ADF_EBADARG, "sigma_color must be >= 0 (FGS.cpp:143)");
+    lut_build_host(sigma_color, table);
+    return ADF_OK;
+}
+
 extern "C" void adf_release_cached_memory(void)
 {
     BlockCache::get().clear();

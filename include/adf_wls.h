@@ -226,6 +226,11 @@ void adf_fgs_destroy(adf_fgs_t* h);
  * user: no host synchronisation) and the weight tables by (device, sigma) (16 of them).  This returns all of it to the
  * driver; it waits for the blocks' last users. */
 void adf_release_cached_memory(void);
+/* The weight table of a sigma_color exactly as the filters build it (FGS.cpp:150-154, 663-675: 3*256*256 entries
+ * -exp(-sqrt(i)/sigma) through the host's libm; built by several threads, the underflowed tail stored as -0.0f without
+ * calling libm).  Host only -- no device is touched: the CPU test suite compares it bit for bit with the oracle's table. */
+#define ADF_WEIGHT_TABLE_LEVELS (3 * 256 * 256)
+int adf_weight_table_host(float sigma_color, float* table, int levels);
 int adf_fgs_get_device(const adf_fgs_t* h, int* device);
 
 /* FastGlobalSmootherFilter::filter(src, dst) (EF.hpp:370, FGS.cpp:182-233).

@@ -99,3 +99,25 @@ def test_synthetic_example_shape_and_determinism():
     for cid, c in synthetic.CONFIGS.items():
         x, y, w, h = c["roi"]
         assert x + w == c["W"] and h == c["H"]
+
+
+def test_weight_table_equals_the_oracles_for_a_sweep_of_sigmas():
+    """The library builds the table by threads and stores the tail where the exponential has underflowed instead of
+    computing it (adf_api.hip: lut_build_host): every entry must still carry the bits libm gives the oracle."""
+    import ctypes as C
+
+    import numpy as np
+
+    import oracle
+    from addingdisparityfiltering_amd import _lib
+
+    n = 3 * 256 * 256
+    sigmas = [0.05, 0.3, 0.999, 1.0, 1.5, 2.0, 3.0, 4.02, 4.03, 4.05, 4.5, 7.0, 25.0, 100.0, 1000.0]
+    sigmas += list(np.exp(np.random.default_rng(0).uniform(np.log(0.2), np.log(6.0), 12)))
+    for s in sigmas:
+        got = np.empty(n, np.float32)
+        assert _lib.lib().adf_weight_table_host(C.c_float(s), got.ctypes.data_as(C.c_void_p), n) == 0
+        exp = oracle.lut(np.float32(s))
+        assert np.array_equal(got.view(np.uint32), np.asarray(exp, np.float32).view(np.uint32)), s
+    assert _lib.lib().adf_weight_table_host(C.c_float(1.5), None, n) != 0
+    assert _lib.lib().adf_weight_table_host(C.c_float(1.5), got.ctypes.data_as(C.c_void_p), n - 1) != 0
