@@ -121,3 +121,49 @@ def test_device_filter_where_the_images_are(adf, depth, cn):
     assert torch.equal(vs, want)
     # overlapping but not identical: refused
     assert call(vs, big_s.shape[1] * cn * esz, big_s[:, pad_l + 1:pad_l + 1 + w], big_s.shape[1] * cn * esz) == _lib.ADF_EBADARG
+
+
+@pytest.mark.gpu
+def test_one_shot_calls_from_several_threads(adf):
+    """Four threads, each on its own stream, make and destroy filters of two sizes back to back: blocks and weight tables
+    change hands between threads and streams; every result must equal the one computed alone."""
+    import threading
+
+    import torch
+
+    dev = torch.device("cuda", 0)
+    rng = np.random.default_rng(21)
+    cases = []
+    for k in range(6):
+        w, h = ((640, 360), (481, 203))[k % 2]
+        guide, src = _case(rng, w, h, (1, 3)[k % 2], (np.uint8, np.float32, np.int16)[k % 3], (3, 1)[k % 2])
+        g, s = torch.from_numpy(guide).to(dev), torch.from_numpy(src).to(dev)
+        lam, sig = 1000.0 + 700 * k, 2.0 + 3 * (k % 3)
+        f = adf.createFastGlobalSmootherFilter(g, lam, sig)
+        want = f.filter(s).clone()
+        torch.cuda.synchronize()
+        del f
+        cases.append((g, s, lam, sig, want))
+    errors = []
+
+    def work(tid):
+        try:
+            st = torch.cuda.Stream(dev)
+            with torch.cuda.stream(st):
+                for it in range(25):
+                    g, s, lam, sig, want = cases[(tid + it) % len(cases)]
+                    got = adf.fastGlobalSmootherFilter(g, s, lam, sig)
+                    if it % 5 == 4:
+                        st.synchronize()
+                        if not torch.equal(got, want):
+                            errors.append((tid, it))
+                st.synchronize()
+        except Exception as e:                      # noqa: BLE001
+            errors.append((tid, repr(e)))
+
+    threads = [threading.Thread(target=work, args=(t,)) for t in range(4)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=300)
+    assert not errors, errors
