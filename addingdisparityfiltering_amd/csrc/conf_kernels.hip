@@ -372,27 +372,34 @@ constexpr int CB_COLS = 4;
 #define CB_HALO(RT) (((RT) + CB_COLS - 1) / CB_COLS)                 // halo lanes on each side of a wave
 #define CB_WOUT(RT) ((64 - 2 * CB_HALO(RT)) * CB_COLS)               // output columns per wave: 248 (radius <= 4), 240 (5..8)
 constexpr int CB_MAX_WAVES = 16;
+constexpr int CB_MAX_BAND_ROWS = 2048;                             // output rows of a band (ColSum::lo must not wrap)
 constexpr int CB_MAX_RADIUS = 2 * CB_COLS;
 
 __device__ __forceinline__ int dpp_from_prev(int v) { return __builtin_amdgcn_update_dpp(0, v, 0x138, 0xf, 0xf, false); }  // wave_shr:1
 __device__ __forceinline__ int dpp_from_next(int v) { return __builtin_amdgcn_update_dpp(0, v, 0x130, 0xf, 0xf, false); }  // wave_shl:1
 
 struct ColSum {
-    int s1, lo, hi;
-    // d enters / leaves the column window (exact: sum d, sum (d*d & 0xffff), sum (d*d >> 16))
+    int s1; unsigned lo; int hi;
+    // d enters / leaves the column window.  sum d^2 = 65536 * hi + lo exactly, carried as two 32-bit halves so that the
+    // horizontal sums need no carries: the change q_new - q_old is split into its low 16 bits (added to lo: never
+    // negative, so lo only grows -- by less than 65536 per row, which is why a band is at most CB_MAX_BAND_ROWS rows:
+    // 17 columns x 2064 rows x 65535 < 2^32) and its arithmetic shift by 16 (added to hi).  Round 3: 7 instructions
+    // instead of the 10 of summing (q & 0xffff) and (q >> 16) of both squares separately.
     __device__ __forceinline__ void slide(int dn, int dold)
     {
         const int qn = __mul24(dn, dn), qo = __mul24(dold, dold);
         s1 += dn - dold;
-        lo += (qn & 0xffff) - (qo & 0xffff);
-        hi += (int)((unsigned)qn >> 16) - (int)((unsigned)qo >> 16);
+        const int diff = qn - qo;
+        lo += (unsigned)diff & 0xffffu;
+        hi += diff >> 16;
     }
 };
 
-__device__ __forceinline__ float disc_value(int s1, int lo, int hi, double scale, float roll_off)
+__device__ __forceinline__ float disc_value(int s1, unsigned lo, int hi, double scale, float roll_off)
 {
     const float mean = (float)((double)s1 * scale);
-    const float sq = (float)(((double)hi * 65536.0 + (double)lo) * scale);
+    // (65536 * hi + lo is an integer below 2^53: the fused form is exact, like the product and the sum it replaces)
+    const float sq = (float)(__builtin_fma((double)hi, 65536.0, (double)lo) * scale);
     const float variance = sq - mean * mean;          // DF.cpp:369
     const float v = 1.0f - roll_off * variance;       // DF.cpp:370
     return v < 0.0f ? 0.0f : v;
@@ -409,17 +416,17 @@ template <int J> __device__ __forceinline__ int dpp_prev_n(int v) { if constexpr
 template <int J> __device__ __forceinline__ int dpp_next_n(int v) { if constexpr (J <= 0) return v; else return dpp_next_n<J - 1>(dpp_from_next(v)); }
 
 template <int RT, int J>
-__device__ __forceinline__ void band_neighbours(const int (&p1)[CB_COLS + 1], const int (&pl)[CB_COLS + 1], const int (&ph)[CB_COLS + 1],
-                                                int q, int& h1, int& hl, int& hh)
+__device__ __forceinline__ void band_neighbours(const int (&p1)[CB_COLS + 1], const unsigned (&pl)[CB_COLS + 1], const int (&ph)[CB_COLS + 1],
+                                                int q, int& h1, unsigned& hl, int& hh)
 {
     if constexpr (J >= 1) {
         const int mp = 4 - 4 * J + RT - q, mn = q + RT - 4 * J + 1;      // columns of lane -J / lane +J inside the window
         const int m = mp < 0 ? 0 : (mp > CB_COLS ? CB_COLS : mp), m2 = mn < 0 ? 0 : (mn > CB_COLS ? CB_COLS : mn);
         if (m > 0) {
-            h1 += dpp_prev_n<J>(p1[CB_COLS] - p1[CB_COLS - m]); hl += dpp_prev_n<J>(pl[CB_COLS] - pl[CB_COLS - m]);
+            h1 += dpp_prev_n<J>(p1[CB_COLS] - p1[CB_COLS - m]); hl += (unsigned)dpp_prev_n<J>((int)(pl[CB_COLS] - pl[CB_COLS - m]));
             hh += dpp_prev_n<J>(ph[CB_COLS] - ph[CB_COLS - m]);
         }
-        if (m2 > 0) { h1 += dpp_next_n<J>(p1[m2]); hl += dpp_next_n<J>(pl[m2]); hh += dpp_next_n<J>(ph[m2]); }
+        if (m2 > 0) { h1 += dpp_next_n<J>(p1[m2]); hl += (unsigned)dpp_next_n<J>((int)pl[m2]); hh += dpp_next_n<J>(ph[m2]); }
         band_neighbours<RT, J - 1>(p1, pl, ph, q, h1, hl, hh);
     }
 }
@@ -428,14 +435,16 @@ template <int RT>
 __device__ __forceinline__ void band_row_values(const ColSum (&V)[CB_COLS], double scale, float roll_off, float (&out)[CB_COLS])
 {
     static_assert(RT >= 1 && RT <= 2 * CB_COLS, "the halo must fit two lanes");
-    int p1[CB_COLS + 1], pl[CB_COLS + 1], ph[CB_COLS + 1];           // prefix sums P[i] = V[0] + .. + V[i-1]
-    p1[0] = pl[0] = ph[0] = 0;
+    int p1[CB_COLS + 1], ph[CB_COLS + 1];                            // prefix sums P[i] = V[0] + .. + V[i-1]
+    unsigned pl[CB_COLS + 1];
+    p1[0] = ph[0] = 0; pl[0] = 0u;
 #pragma unroll
     for (int i = 0; i < CB_COLS; i++) { p1[i + 1] = p1[i] + V[i].s1; pl[i + 1] = pl[i] + V[i].lo; ph[i + 1] = ph[i] + V[i].hi; }
 #pragma unroll
     for (int q = 0; q < CB_COLS; q++) {
         const int a = q - RT > 0 ? q - RT : 0, b = (q + RT < CB_COLS - 1 ? q + RT : CB_COLS - 1) + 1;
-        int h1 = p1[b] - p1[a], hl = pl[b] - pl[a], hh = ph[b] - ph[a];
+        int h1 = p1[b] - p1[a], hh = ph[b] - ph[a];
+        unsigned hl = pl[b] - pl[a];
         band_neighbours<RT, CB_HALO(RT)>(p1, pl, ph, q, h1, hl, hh);
         out[q] = disc_value(h1, hl, hh, scale, roll_off);
     }
@@ -512,7 +521,7 @@ __device__ __forceinline__ void conf_band_body(const ConfBandArgs& a, const int 
 #pragma unroll
     for (int k = 0; k < K; k++) { ringL[k] = make_int2(0, 0); ringR[k] = make_int2(0, 0); }
 #pragma unroll
-    for (int q = 0; q < CB_COLS; q++) { VL[q].s1 = VL[q].lo = VL[q].hi = 0; VR[q].s1 = VR[q].lo = VR[q].hi = 0; }
+    for (int q = 0; q < CB_COLS; q++) { VL[q].s1 = VL[q].hi = 0; VL[q].lo = 0u; VR[q].s1 = VR[q].hi = 0; VR[q].lo = 0u; }
 
     // rows n+1 and n+2 are in flight while row n is reduced
     v2i_u pfL0 = load(baseL, a.sL, 0), pfR0 = load(baseR, a.sR, 0);
@@ -937,6 +946,7 @@ hipError_t launch_conf_band(const ConfBandArgs& a0, int n_pairs, hipStream_t st)
     int rpb = (a.g.rh + bands - 1) / bands;
     const int min_rpb = 2 * a.radius > 4 ? 2 * a.radius : 4;     // (at least as many output rows as halo rows)
     if (rpb < min_rpb) rpb = min_rpb;
+    if (rpb > CB_MAX_BAND_ROWS) rpb = CB_MAX_BAND_ROWS;
     if (rpb > a.g.rh) rpb = a.g.rh;
     a.rows_per_band = rpb;
     const dim3 grid((a.g.rh + rpb - 1) / rpb, n_pairs), block(64 * waves);
@@ -987,6 +997,7 @@ hipError_t launch_prep_small(const ConfBandArgs& c0, const WeightArgs& w, const 
     int rpb = 2 * c0.radius > 4 ? 2 * c0.radius : 4;
     const int rows_all = g.rh * n_pairs;
     if (rpb < (rows_all + 255) / 256) rpb = (rows_all + 255) / 256;
+    if (rpb > CB_MAX_BAND_ROWS) rpb = CB_MAX_BAND_ROWS;
     if (rpb > g.rh) rpb = g.rh;
     a.c.rows_per_band = rpb;
     a.nC = (g.rh + rpb - 1) / rpb;
