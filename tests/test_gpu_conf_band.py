@@ -236,3 +236,39 @@ def test_batches_keep_the_two_stream_preparation(adf):
     f.setDepthDiscontinuityRadius(2)
     f.filter(dl, view, None, -dl, roi)
     assert f.getLastPath() == adf.PATH_CONF_BAND | adf.PATH_FUSED_FIRST_PASS
+
+
+@pytest.mark.gpu
+def test_tall_single_band_is_cut_at_the_row_cap():
+    """The band kernel's low-half sum only grows (conf_kernels.hip: ColSum::slide), so a band is at most 2048 output rows.
+    ADF_CONF_BANDS_TOTAL=1 asks for ONE band per image (a schedule only hundreds of pairs per call would produce): a
+    4300-row frame at the widest radius, disparities with large squares, must come out in several bands, bit for bit.
+    A child process, because the switch is read once per process."""
+    import os
+    import subprocess
+    import sys
+
+    code = r'''
+import numpy as np, sys, os
+sys.path.insert(0, os.getcwd())
+import addingdisparityfiltering_amd as adf, oracle
+rng = np.random.default_rng(2)
+w, h, radius = 192, 4300, 8
+dl = rng.integers(-32768, 32767, (h, w)).astype(np.int16)
+dr = rng.integers(-32768, 32767, (h, w)).astype(np.int16)
+dl[:, ::3] = 255 * 128 + 127           # squares whose low halves are close to the maximum
+view = rng.integers(0, 256, (h, w, 3), dtype=np.uint8)
+roi = (16, 0, w - 16, h)
+p = oracle.default_params(threads=8, sigma_color=1.5, disc_radius=radius)
+exp, exp_conf = oracle.wls_filter(dl, view, dr, roi, p)
+f = adf.createDisparityWLSFilterGeneric(True)
+f.setSolver(adf.SOLVER_WAVE); f.setSigmaColor(1.5); f.setDepthDiscontinuityRadius(radius)
+got = f.filter(dl, view, None, dr, roi)
+assert f.getLastPath() & adf.PATH_CONF_BAND
+assert np.array_equal(f.getConfidenceMap(), exp_conf)
+print("ok")
+'''
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, ADF_CONF_BANDS_TOTAL="1", ADF_MERGE_SMALL="0")
+    r = subprocess.run([sys.executable, "-c", code], cwd=root, env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "ok" in r.stdout, r.stderr[-2000:]
