@@ -167,3 +167,37 @@ def test_one_shot_calls_from_several_threads(adf):
     for t in threads:
         t.join(timeout=300)
     assert not errors, errors
+
+
+@pytest.mark.gpu
+def test_device_filter_call_captured_into_a_graph(adf):
+    """adf_fgs_filter_device queues kernels only: it can be captured and replayed; the handle's ordering event is left
+    alone once a call has been captured (adf_api.hip: fgs_end), and such a handle is freed, not cached, at destruction."""
+    import torch
+
+    dev = torch.device("cuda", 0)
+    rng = np.random.default_rng(13)
+    guide, src = _case(rng, 640, 360, 3, np.float32, 3)
+    g, s = torch.from_numpy(guide).to(dev), torch.from_numpy(src).to(dev)
+    f = adf.createFastGlobalSmootherFilter(g, 4000.0, 9.0)
+    want = f.filter(s).clone()
+    torch.cuda.synchronize()
+    dst = torch.zeros_like(s)
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        f.filter(s, dst)
+    for _ in range(3):
+        dst.zero_()
+        graph.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(dst, want)
+    s2 = s.flip(0).contiguous()
+    want2 = adf.createFastGlobalSmootherFilter(g, 4000.0, 9.0).filter(s2).clone()
+    s.copy_(s2)                                   # the graph reads the same buffer
+    graph.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(dst, want2)
+    del graph, f
+    got = adf.fastGlobalSmootherFilter(g, s, 4000.0, 9.0)      # the library goes on working after the captured handle is gone
+    torch.cuda.synchronize()
+    assert torch.equal(got, want2)
