@@ -186,15 +186,23 @@ __global__ void __launch_bounds__(256) resize_linear_kernel(ResizeArgs a)
                 }
                 int16_t* d = reinterpret_cast<int16_t*>(drow) + dx0;
                 if (full && (reinterpret_cast<uintptr_t>(d) & 7u) == 0)
-                    *reinterpret_cast<uint2*>(d) = make_uint2((unsigned)(unsigned short)q[0] | ((unsigned)(unsigned short)q[1] << 16),
-                                                              (unsigned)(unsigned short)q[2] | ((unsigned)(unsigned short)q[3] << 16));
+                {
+                    typedef unsigned v2u __attribute__((ext_vector_type(2)));
+                    const v2u o = {(unsigned)(unsigned short)q[0] | ((unsigned)(unsigned short)q[1] << 16),
+                                   (unsigned)(unsigned short)q[2] | ((unsigned)(unsigned short)q[3] << 16)};
+                    __builtin_nontemporal_store(o, reinterpret_cast<v2u*>(d));   // (read next from HBM anyway: -7 % on the kernels)
+                }
                 else {
     #pragma unroll
                     for (int c = 0; c < RC; c++) if (dx0 + c < a.dw) d[c] = q[c];
                 }
             } else {
                 float* d = reinterpret_cast<float*>(drow) + dx0;
-                if (full && (reinterpret_cast<uintptr_t>(d) & 15u) == 0) *reinterpret_cast<float4*>(d) = make_float4(v[0], v[1], v[2], v[3]);
+                if (full && (reinterpret_cast<uintptr_t>(d) & 15u) == 0) {
+                    typedef float v4f __attribute__((ext_vector_type(4)));
+                    const v4f o = {v[0], v[1], v[2], v[3]};
+                    __builtin_nontemporal_store(o, reinterpret_cast<v4f*>(d));
+                }
                 else {
     #pragma unroll
                     for (int c = 0; c < RC; c++) if (dx0 + c < a.dw) d[c] = v[c];
