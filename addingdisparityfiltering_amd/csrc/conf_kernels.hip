@@ -940,14 +940,14 @@ hipError_t launch_conf_band(const ConfBandArgs& a0, int n_pairs, hipStream_t st)
         // 1242x375 per call lost 6 % with one tall band per frame)
         int per_cu = conf_band_resident(a.radius, 64 * waves, conf_band_lds(a.g.rw, a.radius), dev);
         if (per_cu < 1) per_cu = 1;
-        // (after the slide's instruction diet the radius 1..2 kernels -- five waves per SIMD, so the weight kernel's waves
-        // still fit beside them -- do better with a band on EVERY CU: 12.81-13.24 against 13.05-13.20 ms per 64 x 4K step,
-        // four alternating runs each; the radius 3..8 kernels keep the quarter free: StereoBM factory's geometry 13.79
-        // against 14.04)
+        // (after the slide's instruction diet the radius 1..3 kernels -- whose registers leave room for the weight kernel's
+        // waves beside them -- do better with a band on EVERY CU: radius 2 12.81-13.24 against 13.05-13.20 ms per 64 x 4K
+        // step, four alternating runs each; radius 3 12.78-13.22 against 13.18-13.33; the radius 4..8 kernels keep the
+        // quarter free: radius 4 13.28-13.73 against 13.62-13.99, StereoBM factory's geometry 13.50-13.58 against 13.76)
         static const int quarters_env = [] { const char* e = getenv("ADF_CONF_BAND_QUARTERS"); return e ? atoi(e) : 0; }();   // A/B knob
         // (narrow ROIs, whose small band workgroups share a CU, keep the quarter free at every radius: 256 frames of
         // 1242x375 per call 2.95-2.97 against 3.06 ms)
-        const int quarters = quarters_env >= 1 && quarters_env <= 4 ? quarters_env : (a.radius <= 2 && per_cu == 1 ? 4 : 3);
+        const int quarters = quarters_env >= 1 && quarters_env <= 4 ? quarters_env : (a.radius <= 3 && per_cu == 1 ? 4 : 3);
         bands_total = cus * quarters / 4 * per_cu;
     }
     int bands = (bands_total + n_pairs - 1) / n_pairs;
