@@ -371,6 +371,7 @@ __global__ void __launch_bounds__(NT) conf_left_kernel(ConfLeftArgs a)
 constexpr int CB_COLS = 4;
 #define CB_HALO(RT) (((RT) + CB_COLS - 1) / CB_COLS)                 // halo lanes on each side of a wave
 #define CB_WOUT(RT) ((64 - 2 * CB_HALO(RT)) * CB_COLS)               // output columns per wave: 248 (radius <= 4), 240 (5..8)
+#define CB_RLDS(RT) ((RT) >= 4 && (RT) <= 6)                        // right view's row ring in LDS (conf_band_body)
 constexpr int CB_MAX_WAVES = 16;
 constexpr int CB_MAX_BAND_ROWS = 2048;                             // output rows of a band (ColSum::lo must not wrap)
 constexpr int CB_MAX_RADIUS = 2 * CB_COLS;
@@ -456,7 +457,14 @@ template <int RT>
 __device__ __forceinline__ void conf_band_body(const ConfBandArgs& a, const int band, const size_t pz, unsigned char* smem)
 {
     constexpr int K = 2 * RT + 1;
-    constexpr int RING = RT + 2;                       // raw right rows kept in LDS (centre row + one row of slack for the slowest wave)
+    // Radius 4..6: the right view's K raw rows live in LDS only (they are parked there for the gather anyway) and the row
+    // that leaves the column window is read back from it, instead of a second register ring: 18..26 registers fewer per
+    // lane, which is what lets a wave of the weight kernel sit beside the band's four waves on a SIMD (the radius 1..3
+    // kernels always could; radius 7..8 would not fit their K + 1 rows into LDS at 4K widths and keep the registers).
+    constexpr bool RLDS = CB_RLDS(RT);
+    // raw right rows kept in LDS: the centre row + one row of slack for the slowest wave; with RLDS all K rows + the one
+    // being written (row n - K is read before this iteration's barrier, row n written before it: never the same slot)
+    constexpr int RING = RLDS ? K + 1 : RT + 2;
     typedef int v2i_u __attribute__((ext_vector_type(2), aligned(2)));
     typedef float v4f_u __attribute__((ext_vector_type(4), aligned(4)));
     const Geom& g = a.g;
@@ -516,10 +524,13 @@ __device__ __forceinline__ void conf_band_body(const ConfBandArgs& a, const int 
     };
 #define CB_ELEM(P, q) ((q) == 0 ? (int)(short)((P).x & 0xffff) : (q) == 1 ? ((P).x >> 16) : (q) == 2 ? (int)(short)((P).y & 0xffff) : ((P).y >> 16))
 
-    int2 ringL[K], ringR[K];
+    int2 ringL[K], ringR[RLDS ? 1 : K];
     ColSum VL[CB_COLS], VR[CB_COLS];
 #pragma unroll
-    for (int k = 0; k < K; k++) { ringL[k] = make_int2(0, 0); ringR[k] = make_int2(0, 0); }
+    for (int k = 0; k < K; k++) { ringL[k] = make_int2(0, 0); if (!RLDS) ringR[k] = make_int2(0, 0); }
+    // (RLDS) an 8-byte LDS read needs an 8-byte aligned address: true for every lane away from the image edges
+    // (lcol = vbase, a multiple of 4 columns); waves with an edge lane read 2-byte aligned
+    const bool unaligned_wave = RLDS && __builtin_amdgcn_ballot_w64((lcol & 3) != 0) != 0;
 #pragma unroll
     for (int q = 0; q < CB_COLS; q++) { VL[q].s1 = VL[q].hi = 0; VL[q].lo = 0u; VR[q].s1 = VR[q].hi = 0; VR[q].lo = 0u; }
 
@@ -535,12 +546,25 @@ __device__ __forceinline__ void conf_band_body(const ConfBandArgs& a, const int 
                 pfL0 = pfL1; pfR0 = pfR1;
                 pfL1 = load(baseL, a.sL, n + 2); pfR1 = load(baseR, a.sR, n + 2);
                 // vertical: row n enters the column windows, row n-K leaves (zeros during the first K rows)
+                int2 oldR;
+                if constexpr (RLDS) {
+                    // row n-K of the right view, this lane's four (virtual) columns: the same window + permute as the
+                    // global load, from the LDS ring (zeros while the window fills)
+                    const int16_t* rp = draw + (n >= K ? (n - K) % RING : 0) * rwp + lcol;
+                    v2i_u q2;
+                    if (unaligned_wave) q2 = *reinterpret_cast<const v2i_u*>(rp);
+                    else { const int2 t = *reinterpret_cast<const int2*>(rp); q2.x = t.x; q2.y = t.y; }
+                    oldR = permute(q2);
+                    if (n < K) oldR = make_int2(0, 0);
+                } else
+                    oldR = ringR[s];
 #pragma unroll
                 for (int q = 0; q < CB_COLS; q++) {
                     VL[q].slide(CB_ELEM(curL, q), CB_ELEM(ringL[s], q));
-                    VR[q].slide(CB_ELEM(curR, q), CB_ELEM(ringR[s], q));
+                    VR[q].slide(CB_ELEM(curR, q), CB_ELEM(oldR, q));
                 }
-                ringL[s] = curL; ringR[s] = curR;
+                ringL[s] = curL;
+                if constexpr (!RLDS) ringR[s] = curR;
                 float cl[CB_COLS], cr[CB_COLS];
                 const bool complete = n >= 2 * RT;                      // windows centred on input row n-RT are complete
                 if (complete) {                                          // (one basic block: the DPP fetches fold into their adds)
@@ -878,7 +902,12 @@ hipError_t launch_discontinuity(const DiscArgs& a, int n_pairs, hipStream_t st)
 
 int conf_left_max_radius() { return 8; }
 
-static inline size_t conf_band_lds(int rw, int radius) { const size_t rwp = (size_t)((rw + 3) & ~3); return 2 * rwp * 4 + (size_t)(radius + 2) * rwp * 2; }
+static inline size_t conf_band_lds(int rw, int radius)
+{
+    const size_t rwp = (size_t)((rw + 3) & ~3);
+    const size_t ring = CB_RLDS(radius) ? 2 * (size_t)radius + 2 : (size_t)radius + 2;     // rows of raw right disparities
+    return 2 * rwp * 4 + ring * rwp * 2;
+}
 
 bool conf_band_fits(const Geom& g, int radius)
 {
@@ -940,14 +969,16 @@ hipError_t launch_conf_band(const ConfBandArgs& a0, int n_pairs, hipStream_t st)
         // 1242x375 per call lost 6 % with one tall band per frame)
         int per_cu = conf_band_resident(a.radius, 64 * waves, conf_band_lds(a.g.rw, a.radius), dev);
         if (per_cu < 1) per_cu = 1;
-        // (after the slide's instruction diet the radius 1..3 kernels -- whose registers leave room for the weight kernel's
-        // waves beside them -- do better with a band on EVERY CU: radius 2 12.81-13.24 against 13.05-13.20 ms per 64 x 4K
-        // step, four alternating runs each; radius 3 12.78-13.22 against 13.18-13.33; the radius 4..8 kernels keep the
-        // quarter free: radius 4 13.28-13.73 against 13.62-13.99, StereoBM factory's geometry 13.50-13.58 against 13.76)
+        // (after the slide's instruction diet the kernels whose registers leave room for a wave of the weight kernel beside
+        // the band's four on a SIMD -- at most 104 per lane: radius 1..3, and 4..5 since their right-view ring moved to
+        // LDS -- do better with a band on EVERY CU: radius 2 12.81-13.24 against 13.05-13.20 ms per 64 x 4K step, four
+        // alternating runs each; radius 3 12.78-13.22 against 13.18-13.33; StereoBM factory's geometry (radius 5)
+        // 13.04-13.17 against 13.46-13.63, and 13.59-13.64 with the ring in registers; radius 4 13.02-13.17 against 13.54.
+        // Radius 6..8 (108..128 registers) keep the quarter free: radius 6 13.65-13.78 against 13.92)
         static const int quarters_env = [] { const char* e = getenv("ADF_CONF_BAND_QUARTERS"); return e ? atoi(e) : 0; }();   // A/B knob
         // (narrow ROIs, whose small band workgroups share a CU, keep the quarter free at every radius: 256 frames of
         // 1242x375 per call 2.95-2.97 against 3.06 ms)
-        const int quarters = quarters_env >= 1 && quarters_env <= 4 ? quarters_env : (a.radius <= 3 && per_cu == 1 ? 4 : 3);
+        const int quarters = quarters_env >= 1 && quarters_env <= 4 ? quarters_env : (a.radius <= 5 && per_cu == 1 ? 4 : 3);
         bands_total = cus * quarters / 4 * per_cu;
     }
     int bands = (bands_total + n_pairs - 1) / n_pairs;
