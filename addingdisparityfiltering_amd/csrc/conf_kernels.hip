@@ -371,7 +371,7 @@ __global__ void __launch_bounds__(NT) conf_left_kernel(ConfLeftArgs a)
 constexpr int CB_COLS = 4;
 #define CB_HALO(RT) (((RT) + CB_COLS - 1) / CB_COLS)                 // halo lanes on each side of a wave
 #define CB_WOUT(RT) ((64 - 2 * CB_HALO(RT)) * CB_COLS)               // output columns per wave: 248 (radius <= 4), 240 (5..8)
-#define CB_RLDS(RT) ((RT) >= 4 && (RT) <= 6)                        // right view's row ring in LDS (conf_band_body)
+#define CB_RLDS(RT) ((RT) >= 4)                                     // right view's row ring in LDS by default (conf_band_body)
 constexpr int CB_MAX_WAVES = 16;
 constexpr int CB_MAX_BAND_ROWS = 2048;                             // output rows of a band (ColSum::lo must not wrap)
 constexpr int CB_MAX_RADIUS = 2 * CB_COLS;
@@ -453,15 +453,15 @@ __device__ __forceinline__ void band_row_values(const ColSum (&V)[CB_COLS], doub
 
 // (band `band` of image `pz`; smem = the workgroup's dynamic LDS.  Waves past the ROI's width own no columns and only
 // keep the barriers company: the merged preparation kernel launches at least four waves per block.)
-template <int RT>
+template <int RT, bool RLDS = CB_RLDS(RT)>
 __device__ __forceinline__ void conf_band_body(const ConfBandArgs& a, const int band, const size_t pz, unsigned char* smem)
 {
     constexpr int K = 2 * RT + 1;
-    // Radius 4..6: the right view's K raw rows live in LDS only (they are parked there for the gather anyway) and the row
-    // that leaves the column window is read back from it, instead of a second register ring: 18..26 registers fewer per
-    // lane, which is what lets a wave of the weight kernel sit beside the band's four waves on a SIMD (the radius 1..3
-    // kernels always could; radius 7..8 would not fit their K + 1 rows into LDS at 4K widths and keep the registers).
-    constexpr bool RLDS = CB_RLDS(RT);
+    // RLDS (radius 4..8 wherever K + 1 rows of the ROI's width fit the LDS: always up to radius 6, up to ~3700 columns at
+    // radius 7 and ~3300 at radius 8): the right view's K raw rows live in LDS only (they are parked there for the gather
+    // anyway) and the row that leaves the column window is read back from it, instead of a second register ring: 18..34
+    // registers fewer per lane -- at radius 4..5 that is what lets a wave of the weight kernel sit beside the band's
+    // four waves on a SIMD (the radius 1..3 kernels always could), at radius 6..8 it ends the register spills.
     // raw right rows kept in LDS: the centre row + one row of slack for the slowest wave; with RLDS all K rows + the one
     // being written (row n - K is read before this iteration's barrier, row n written before it: never the same slot)
     constexpr int RING = RLDS ? K + 1 : RT + 2;
@@ -611,11 +611,11 @@ __device__ __forceinline__ void conf_band_body(const ConfBandArgs& a, const int 
 #undef CB_ELEM
 }
 
-template <int RT>
+template <int RT, bool RLDS = CB_RLDS(RT)>
 __global__ void __launch_bounds__(64 * CB_MAX_WAVES) conf_band_kernel(ConfBandArgs a)
 {
     extern __shared__ __align__(16) unsigned char smem[];
-    conf_band_body<RT>(a, blockIdx.x, blockIdx.y, smem);
+    conf_band_body<RT, RLDS>(a, blockIdx.x, blockIdx.y, smem);
 }
 
 constexpr int OUT_ROWS = 16; // rows per block of outside_kernel
@@ -902,39 +902,58 @@ hipError_t launch_discontinuity(const DiscArgs& a, int n_pairs, hipStream_t st)
 
 int conf_left_max_radius() { return 8; }
 
+constexpr size_t CB_LDS_LIMIT = 150 * 1024;
+static inline size_t conf_band_lds_rows(int rw, size_t ring_rows) { const size_t rwp = (size_t)((rw + 3) & ~3); return 2 * rwp * 4 + ring_rows * rwp * 2; }
+// does the band kernel keep the right view's whole row ring in LDS for this width?
+static inline bool conf_band_rlds(int rw, int radius) { return CB_RLDS(radius) && conf_band_lds_rows(rw, 2 * (size_t)radius + 2) <= CB_LDS_LIMIT; }
 static inline size_t conf_band_lds(int rw, int radius)
 {
-    const size_t rwp = (size_t)((rw + 3) & ~3);
-    const size_t ring = CB_RLDS(radius) ? 2 * (size_t)radius + 2 : (size_t)radius + 2;     // rows of raw right disparities
-    return 2 * rwp * 4 + ring * rwp * 2;
+    return conf_band_lds_rows(rw, conf_band_rlds(rw, radius) ? 2 * (size_t)radius + 2 : (size_t)radius + 2);   // rows of raw right disparities
 }
 
 bool conf_band_fits(const Geom& g, int radius)
 {
     return radius >= 1 && radius <= CB_MAX_RADIUS && g.rw >= 8 && g.rw > radius && g.rw <= CB_MAX_WAVES * CB_WOUT(radius) &&
-           g.rh > radius && conf_band_lds(g.rw, radius) <= 150 * 1024;
+           g.rh > radius && conf_band_lds(g.rw, radius) <= CB_LDS_LIMIT;
 }
 
 // Band workgroups of this shape a CU holds at once (occupancy query, remembered per radius for the last shape asked).
-static int conf_band_resident(int radius, int threads, size_t lds, int dev)
+static int conf_band_resident(int radius, bool rlds, int threads, size_t lds, int dev)
 {
-    struct Memo { int dev, threads; size_t lds; int value; };
+    struct Memo { int dev, threads; size_t lds; bool rlds; int value; };
     static Memo memo[CB_MAX_RADIUS + 1] = {};
     static std::mutex mu;
     {
         std::lock_guard<std::mutex> lk(mu);
         const Memo& m = memo[radius];
-        if (m.value > 0 && m.dev == dev && m.threads == threads && m.lds == lds) return m.value;
+        if (m.value > 0 && m.dev == dev && m.threads == threads && m.lds == lds && m.rlds == rlds) return m.value;
     }
     int v = 0;
     hipError_t e = hipErrorInvalidValue;
+    // (radius 1..3 have no LDS-ring variant, 4..6 always use it, 7..8 by the ROI's width)
 #define ADF_CBQ(RR) case RR: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&v, conf_band_kernel<RR>, threads, lds); break;
-    switch (radius) { ADF_CBQ(1) ADF_CBQ(2) ADF_CBQ(3) ADF_CBQ(4) ADF_CBQ(5) ADF_CBQ(6) ADF_CBQ(7) ADF_CBQ(8) }
+#define ADF_CBQ2(RR) case RR: e = rlds ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&v, conf_band_kernel<RR, true>, threads, lds) \
+                                       : hipOccupancyMaxActiveBlocksPerMultiprocessor(&v, conf_band_kernel<RR, false>, threads, lds); break;
+    switch (radius) { ADF_CBQ(1) ADF_CBQ(2) ADF_CBQ(3) ADF_CBQ(4) ADF_CBQ(5) ADF_CBQ(6) ADF_CBQ2(7) ADF_CBQ2(8) }
 #undef ADF_CBQ
+#undef ADF_CBQ2
     if (e != hipSuccess || v < 1) { (void)hipGetLastError(); v = 1; }
     std::lock_guard<std::mutex> lk(mu);
-    memo[radius] = Memo{dev, threads, lds, v};
+    memo[radius] = Memo{dev, threads, lds, rlds, v};
     return v;
+}
+
+template <int RR, bool RL>
+static hipError_t launch_conf_band_variant(const ConfBandArgs& a, dim3 grid, dim3 block, size_t lds, hipStream_t st)
+{
+    // (the attribute belongs to the function ON THE CURRENT DEVICE and a process may hold handles on several: no cache)
+    if (lds > 48 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conf_band_kernel<RR, RL>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL((conf_band_kernel<RR, RL>), grid, block, lds, st, a);
+    return hipSuccess;
 }
 
 hipError_t launch_conf_band(const ConfBandArgs& a0, int n_pairs, hipStream_t st)
@@ -967,7 +986,7 @@ hipError_t launch_conf_band(const ConfBandArgs& a0, int n_pairs, hipStream_t st)
         // fill a SIMD's registers with four waves: nothing runs BESIDE them, but the fill no longer crawls behind them)
         // (narrow ROIs make small band workgroups, several of which share a CU: ask the runtime how many -- 256 frames of
         // 1242x375 per call lost 6 % with one tall band per frame)
-        int per_cu = conf_band_resident(a.radius, 64 * waves, conf_band_lds(a.g.rw, a.radius), dev);
+        int per_cu = conf_band_resident(a.radius, conf_band_rlds(a.g.rw, a.radius), 64 * waves, conf_band_lds(a.g.rw, a.radius), dev);
         if (per_cu < 1) per_cu = 1;
         // (after the slide's instruction diet the kernels whose registers leave room for a wave of the weight kernel beside
         // the band's four on a SIMD -- at most 104 per lane: radius 1..3, and 4..5 since their right-view ring moved to
@@ -991,17 +1010,20 @@ hipError_t launch_conf_band(const ConfBandArgs& a0, int n_pairs, hipStream_t st)
     const dim3 grid((a.g.rh + rpb - 1) / rpb, n_pairs), block(64 * waves);
     size_t lds = conf_band_lds(a.g.rw, a.radius);
     if (a.lds_floor > lds) lds = a.lds_floor;         // (occupancy control: see ConfBandArgs::lds_floor)
-    // (the attribute belongs to the function ON THE CURRENT DEVICE and a process may hold handles on several: no cache)
-#define ADF_CB(RR)                                                                                          \
-    case RR:                                                                                                \
-        if (lds > 48 * 1024) {                                                                              \
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conf_band_kernel<RR>),         \
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);       \
-            if (e != hipSuccess) return e;                                                                  \
-        }                                                                                                   \
-        hipLaunchKernelGGL(conf_band_kernel<RR>, grid, block, lds, st, a);                                  \
-        break;
-    switch (a.radius) { ADF_CB(1) ADF_CB(2) ADF_CB(3) ADF_CB(4) ADF_CB(5) ADF_CB(6) ADF_CB(7) ADF_CB(8) }
+    const bool rl = conf_band_rlds(a.g.rw, a.radius);
+    hipError_t le = hipErrorInvalidValue;
+#define ADF_CB(RR, RL) le = launch_conf_band_variant<RR, RL>(a, grid, block, lds, st)
+    switch (a.radius) {
+    case 1: ADF_CB(1, false); break;
+    case 2: ADF_CB(2, false); break;
+    case 3: ADF_CB(3, false); break;
+    case 4: ADF_CB(4, true); break;
+    case 5: ADF_CB(5, true); break;
+    case 6: ADF_CB(6, true); break;
+    case 7: if (rl) ADF_CB(7, true); else ADF_CB(7, false); break;
+    case 8: if (rl) ADF_CB(8, true); else ADF_CB(8, false); break;
+    }
+    if (le != hipSuccess) return le;
 #undef ADF_CB
     return hipGetLastError();
 }
