@@ -340,6 +340,7 @@ __global__ void __launch_bounds__(256) bm_match_kernel(MatchArgs a)
             const int dd = pv + nv - 2 * sb + abs(pv - nv);
             int16_t out = (int16_t)(((kb + mindisp) * 256 + (dd != 0 ? (pv - nv) * 256 / dd : 0) + 15) >> 4);
             if ((int)tex[r][j] < texthr) out = filtered;
+            if (y < W2 || y >= a.H - W2) out = filtered;                 // rows without a full window (calib3d's valid rectangle)
             if (UNIQ && uniq > 0) {                                       // (a view of the launch may have the test off)
                 const int thresh = sb + sb * uniq / 100;
                 uint32_t other = min(lmin[r][j], rmin[r][j]);

@@ -315,6 +315,9 @@ def worker(args):
         if not dry:
             torch.cuda.synchronize()
 
+    if dry and os.environ.get("ADF_BENCH_TEST_FAIL_RANK") == str(rank):     # tests/test_bench_launcher.py: a rank that dies
+        sys.stderr.write("bench: rank %d: failing on request (test hook, --dry-run only)\n" % rank)
+        os._exit(7)
     cfg = synthetic.CONFIGS[args.config]
     W, H, roi, ch, radius = cfg["W"], cfg["H"], cfg["roi"], cfg["channels"], cfg["radius"]
     roi_kind = args.roi
@@ -456,32 +459,43 @@ def worker(args):
                           prof, checked_all, checksum, ranks_info, path, scatter_ms, gather_ms, pipelined,
                           None if f is None else round(f.workspaceBytes() / 1e9, 2))
 
+    import threading
+
+    emit_lock, emitted = threading.Lock(), []
+
     def emit():
-        if line is not None:
+        with emit_lock:                                      # the watchdog thread and the main thread may both get here:
+            if emitted or line is None:                      # the line is written once
+                return
+            emitted.append(True)
             json_out.write(json.dumps(line) + "\n")
             json_out.flush()
 
     # ---- extra legs.  None of them is part of `value`, none may cost the line: every one runs inside try/except, and
     # at N > 1 -- where a stuck transfer would hang all ranks -- under a watchdog that prints the line as it stands
-    # and ends every rank with status 0.
+    # (marked "extra_legs_hung": true) and ends the rank with status 5, so that a hung transfer is never reported as a
+    # clean run: the launcher relays the line AND returns non-zero.
     watchdog = None
     if world > 1:
-        import threading
-
         def bail():
-            if line is not None:
-                line.setdefault("rccl_legs", {})
-                if isinstance(line["rccl_legs"], dict):
+            with emit_lock:
+                already = bool(emitted)
+                if line is not None and not already:
+                    line["extra_legs_hung"] = True
+                    if not isinstance(line.get("rccl_legs"), dict):
+                        line["rccl_legs"] = {}
                     line["rccl_legs"]["watchdog"] = "extra legs did not finish in %.0f s: line printed without them" % limit
             emit()
             sys.stderr.write("bench: rank %d: extra-leg watchdog fired\n" % rank)
             sys.stderr.flush()
-            os._exit(0)
-        limit = 240.0 + max(0.0, args.cpu_seconds) * 2
+            os._exit(0 if already else 5)
+        limit = float(os.environ.get("ADF_BENCH_WATCHDOG_S", 240.0 + max(0.0, args.cpu_seconds) * 2))
         watchdog = threading.Timer(limit, bail)
         watchdog.daemon = True
         watchdog.start()
 
+    if dry and world > 1 and os.environ.get("ADF_BENCH_TEST_HANG_RANK") == str(rank):   # test hook: a transfer that never ends
+        time.sleep(3600)
     if world > 1 and args.distribution == "local" and args.rccl_legs == "auto":
         legs = None
         try:

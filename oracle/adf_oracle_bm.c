@@ -11,20 +11,23 @@
  * from its documentation and from memory of its structure:
  *   1. x-Sobel prefilter clipped to [-cap, cap] and offset by cap (PREFILTER_XSOBEL, the default);
  *   2. SAD over a blockSize x blockSize window for every disparity in [minDisparity,
- *      minDisparity + numDisparities), rows outside the image replicated;
+ *      minDisparity + numDisparities);
  *   3. winner-take-all (ties go to the LARGEST disparity: the search buffer runs from the largest
  *      disparity down and keeps the first strict minimum), optional texture and uniqueness tests,
  *      parabola-like sub-pixel fit, result in fixed point with 4 fractional bits (CV_16SC1);
- *   4. pixels without a full search range or window column-wise, and rejected pixels, hold
- *      (minDisparity - 1) * 16.
- * Suspected deviations from calib3d's StereoBM, recorded because nothing in the reference tree can settle them
- * (round-1 code review, from memory of OpenCV's source): (a) calib3d may emit disparities for the outer
- * blockSize/2 columns of [lofs, W-rofs) with clamped window columns, where this statement marks them FILTERED --
- * createDisparityWLSFilter cuts exactly that band off the ROI (disparity_filters.cpp:401), so the filter never reads
- * it; (b) calib3d's prefilterXSobel works on row pairs and fills the last row of an odd-height image with the cap
- * value, where this statement filters every row with reflected neighbours -- the difference reaches block sums of
- * the last blockSize/2 rows only, which the same ROI cut removes.  Raw matcher maps may therefore differ from
- * OpenCV's in those bands; the filter's input inside its ROI is unaffected by (a) and by (b) up to the window reach.
+ *   4. pixels without a full search range or a full window (column-wise AND row-wise: the valid rectangle is
+ *      x in [max(maxD, 0) + w/2, W + min(minD, 0) - w/2), y in [w/2, H - w/2), calib3d's getValidDisparityROI over the
+ *      whole image), and rejected pixels, hold (minDisparity - 1) * 16.  The row rule is evidenced by the one raw
+ *      StereoBM map the reference tree publishes: tutorials/images/ambush_5_bm.png is non-zero exactly from row 4 to
+ *      row H-5 and from column 131 on for StereoBM(128, 9) (tests/tutorial_replay.py); until round 4 this statement
+ *      matched rows outside that rectangle with replicated image rows instead.
+ * Suspected deviations from calib3d's StereoBM (round-1 code review, from memory of OpenCV's source): (a) SETTLED in
+ * round 4 -- the suspicion was that calib3d emits disparities for the outer blockSize/2 columns of [lofs, W-rofs)
+ * with clamped window columns; the published ambush_5_bm.png has column 130 empty and column 131 = maxD + w/2 filled
+ * (349 of 428 rows), so calib3d marks that band FILTERED as this statement does; (b) OPEN -- calib3d's
+ * prefilterXSobel works on row pairs and may fill the last row of an odd-height image with the cap value, where this
+ * statement filters every row with reflected neighbours: the difference would reach the block sums of output row
+ * H-1-w/2 of odd-height images only (the tutorial pair has even heights at both resolutions, so it cannot tell).
  * What the reference itself fixes are the conventions around the call: the right-view matcher's
  * parameters (disparity_filters.cpp:421-431), the settings the filter forces on the matcher (:389-390,
  * 399-400: texture threshold 0, uniqueness ratio 0, no speckle filter, no left-right check) and the
@@ -80,6 +83,7 @@ int adf_oracle_bm_compute(const adf_oracle_bm_params* p, const uint8_t* left, pt
         int16_t* drow = disp + (ptrdiff_t)y * dstride;
         for (int x = 0; x < W; x++) drow[x] = filtered;
         if (xe <= xs) continue;
+        if (y < w2 || y >= H - w2) continue;                           /* rows without a full window: see (4) in the header */
         /* texture: sum over the window of |L - cap| */
         for (int x = xs - w2; x < xe + w2; x++) {
             int s = 0;

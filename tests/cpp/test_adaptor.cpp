@@ -80,6 +80,56 @@ int main()
         }
         EXPECT(maxd <= 1); EXPECT(sum <= 320.0 * 240.0 / 256.0);
     }
+    {   // The sample's DEFAULT call (samples/disparity_filtering.cpp:137-141,189; perf_disparity_wls_filter.cpp:76-83):
+        // half-size disparity maps, full-size view.  The adaptor's filter() must create the output at the VIEW's size,
+        // resize inside the call (DF.cpp:239-247,268-284) and report a view-sized confidence map -- checked against the
+        // C-ABI scaled entry point it binds and against the oracle.
+        const int W = 320, H = 240, w = W / 2, h = H / 2;
+        for (bool use_conf : {true, false}) {
+            Mat view, fl, fr; Rect froi;
+            make_example(W, H, 3, 21u, view, fl, fr, froi);
+            Mat dl(h, w, D16S, 1), dr(h, w, D16S, 1);
+            for (int i = 0; i < h; i++) for (int j = 0; j < w; j++) {
+                dl.ptr<int16_t>(i)[j] = (int16_t)(fl.ptr<int16_t>(2 * i)[2 * j] / 2);
+                dr.ptr<int16_t>(i)[j] = (int16_t)(fr.ptr<int16_t>(2 * i)[2 * j] / 2);
+            }
+            Rect roi(froi.x / 2, froi.y / 2, froi.width / 2, froi.height / 2);             // in the maps' coordinates
+            Ptr<DisparityWLSFilter> wls = createDisparityWLSFilterGeneric(use_conf);
+            wls->setLambda(8000.0); wls->setSigmaColor(1.5); wls->setSolver(ADF_SOLVER_EXACT);
+            Mat res;
+            wls->filter(dl, view, res, use_conf ? dr : Mat(), roi);
+            EXPECT(res.rows == H && res.cols == W);                                         // DF.cpp:252,282
+            Rect r = wls->getROI();                          // valid_disp_ROI, in the MAPS' coordinates (DF.cpp:139,229-230;
+            EXPECT(r.x == roi.x && r.y == roi.y && r.width == roi.width && r.height == roi.height);   // the sample doubles it, :196-201)
+            // the C-ABI call the reference-side binding makes
+            adf_wls_t* hh = nullptr;
+            EXPECT(adf_wls_create(&hh, use_conf ? 1 : 0, 0, 0, 0, 0, 0) == ADF_OK);
+            EXPECT(adf_wls_set_lambda(hh, 8000.0) == ADF_OK && adf_wls_set_sigma_color(hh, 1.5) == ADF_OK &&
+                   adf_wls_set_solver(hh, ADF_SOLVER_EXACT) == ADF_OK);
+            Mat direct(H, W, D16S, 1);
+            adf_rect ar{roi.x, roi.y, roi.width, roi.height};
+            EXPECT(adf_wls_filter_scaled_host(hh, 1, dl.ptr<int16_t>(), (ptrdiff_t)dl.step, 0, w, h,
+                                              view.data, (ptrdiff_t)view.step, 0, 3, W, H,
+                                              direct.ptr<int16_t>(), (ptrdiff_t)direct.step, 0,
+                                              use_conf ? dr.ptr<int16_t>() : nullptr, use_conf ? (ptrdiff_t)dr.step : 0, 0, &ar) == ADF_OK);
+            EXPECT(std::memcmp(res.data, direct.data, (size_t)H * direct.step) == 0);
+            // ... and the oracle's statement of the same call
+            adf_oracle_params p; adf_oracle_default_params(&p);
+            p.lambda = 8000.0; p.sigma_color = 1.5; p.use_confidence = use_conf; p.threads = 4;
+            Mat exp(H, W, D16S, 1), conf(H, W, D32F, 1);
+            EXPECT(adf_oracle_wls_filter_scaled(&p, dl.ptr<int16_t>(), use_conf ? dr.ptr<int16_t>() : nullptr, w, h, view.data, 3, W, H,
+                                                roi.x, roi.y, roi.width, roi.height, exp.ptr<int16_t>(), conf.ptr<float>()) == 0);
+            EXPECT(std::memcmp(res.data, exp.data, (size_t)H * exp.step) == 0);
+            if (use_conf) {
+                Mat c = wls->getConfidenceMap();                                            // view-sized (DF.cpp:274)
+                EXPECT(c.rows == H && c.cols == W && std::memcmp(c.data, conf.data, (size_t)H * conf.step) == 0);
+                Mat c2(H, W, D32F, 1);
+                EXPECT(adf_wls_get_confidence_host(hh, 0, c2.ptr<float>(), (ptrdiff_t)c2.step) == ADF_OK);
+                EXPECT(std::memcmp(c.data, c2.data, (size_t)H * c2.step) == 0);
+            }
+            adf_wls_destroy(hh);
+        }
+    }
     {   // SplatSurfaceAccuracy (test_fgs_filter.cpp:59-87) through fastGlobalSmootherFilter
         std::mt19937 rng(0);
         Mat guide(600, 700, D8U, 3), src(600, 700, D16S, 1), res;

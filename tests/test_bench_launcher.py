@@ -79,3 +79,52 @@ def test_worker_failure_propagates():
                        cwd=ROOT, env=_clean_env(), capture_output=True, text=True, timeout=300)
     assert p.returncode != 0
     assert "bench launcher: rank" in p.stderr
+
+
+def test_self_launch_eight_ranks_rehearsal():
+    """BASELINE config 4's world size (8 ranks, one node) on gloo: eight workers, one line, eight identities, the
+    data-path legs (7-peer point-to-point groups, 4 pipelined sub-batches) run and verify themselves."""
+    p = subprocess.run([sys.executable, BENCH, "--gpus", "8", "--dry-run", "--steps", "2", "--warmup", "1", "--pairs", "5"],
+                       cwd=ROOT, env=_clean_env(), capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, p.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 8 and d["world_size"] == 8 and d["launcher"] == "self" and d["dry_run"] is True
+    assert len(d["per_rank_ms_per_step"]) == 8
+    assert [r["rank"] for r in d["ranks"]] == list(range(8)) and len({r["pid"] for r in d["ranks"]}) == 8
+    assert [r["local_rank"] for r in d["ranks"]] == list(range(8))
+    assert "distinct_devices" in d and d["config"]["total_pairs"] == 40 and d["config"]["parallelism"] == "batch-sharded x8"
+    assert d["checksum"] == 5 * 16 * sum(range(1, 9))
+    legs = d["rccl_legs"]
+    assert legs["backend"] == "gloo" and legs["world_size"] == 8
+    assert legs["scattered_shards_equal_locally_generated"] is True and legs["gathered_checksum_matches"] is True
+    pl = legs["pipelined_scatter_filter_gather"]
+    assert pl["sub_batches"] == 4 and pl["output_checksum_matches"] is True
+    assert "extra_legs_hung" not in d
+
+
+def test_rank_five_of_eight_failing_propagates():
+    env = _clean_env()
+    env["ADF_BENCH_TEST_FAIL_RANK"] = "5"
+    p = subprocess.run([sys.executable, BENCH, "--gpus", "8", "--dry-run", "--steps", "1", "--warmup", "0", "--pairs", "2",
+                        "--launch-timeout", "120"],
+                       cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 7, (p.returncode, p.stderr[-2000:])
+    assert "bench launcher: rank 5 exited with code 7" in p.stderr
+    assert p.stdout.strip() == ""                                      # no line from a job that lost a rank
+
+
+def test_hung_extra_leg_prints_the_line_and_fails():
+    """a transfer that never finishes must not end as rc 0.  The watchdog prints the timed line once, marked,
+    and the job exits non-zero."""
+    env = _clean_env()
+    env.update(ADF_BENCH_TEST_HANG_RANK="1", ADF_BENCH_WATCHDOG_S="6")
+    p = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--dry-run", "--steps", "1", "--warmup", "0", "--pairs", "2",
+                        "--launch-timeout", "120"],
+                       cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 5, (p.returncode, p.stderr[-2000:])
+    lines = [ln for ln in p.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, p.stdout
+    d = json.loads(lines[0])
+    assert d["extra_legs_hung"] is True and d["n_gpus"] == 2 and "watchdog" in d["rccl_legs"]

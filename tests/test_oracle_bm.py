@@ -50,9 +50,8 @@ def naive_bm(left, right, nd, wsz, md=0, cap=31, texthr=0, uniq=0):
     maxd = md + nd - 1
     xs, xe = max(maxd, 0) + w2, W - max(-md, 0) - w2
     out = np.full((H, W), (md - 1) * 16, np.int64)
-    yy = np.clip(np.arange(-w2, H + w2), 0, H - 1)
-    for y in range(H):
-        rows = yy[y:y + wsz]
+    for y in range(w2, H - w2):                               # calib3d's valid rectangle: full windows only
+        rows = np.arange(y - w2, y + w2 + 1)
         for x in range(xs, xe):
             lw = L[rows, x - w2:x + w2 + 1]
             S = np.array([np.abs(lw - R[rows, x - w2 - (md + k):x + w2 + 1 - (md + k)]).sum() for k in range(nd)])
