@@ -12,6 +12,7 @@ from .ximgproc import (  # noqa: F401
     PATH_CONF_BAND,
     PATH_FUSED_FIRST_PASS,
     PATH_MERGED_PREP,
+    PATH_SCALED_FUSED,
     SOLVER_EXACT,
     SOLVER_WAVE,
     StereoBM,

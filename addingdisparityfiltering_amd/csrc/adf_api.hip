@@ -407,9 +407,18 @@ static int run_passes_wave(const Geom& g, const SolvePlanes& p, int n_rhs, float
             h.conf_x0 = fuse_first->conf_x0; h.conf_y0 = fuse_first->conf_y0;
             h.dl_in = fuse_first->dl_in; h.dl_stride = fuse_first->dl_stride; h.dl_pair_stride = fuse_first->dl_pair_stride;
             h.dl_x0 = fuse_first->dl_x0; h.dl_y0 = fuse_first->dl_y0;
+            // ... or interpolated from the low-resolution maps in the pass (down-scaled path, DF.cpp:272-274)
+            h.lo_conf = fuse_first->lo_conf; h.lo_conf_stride = fuse_first->lo_conf_stride; h.lo_conf_pair = fuse_first->lo_conf_pair;
+            h.lo_dl = fuse_first->lo_dl; h.lo_dl_stride = fuse_first->lo_dl_stride; h.lo_dl_pair = fuse_first->lo_dl_pair;
+            h.lo_w = fuse_first->lo_w; h.lo_h = fuse_first->lo_h; h.hi_x0 = fuse_first->hi_x0; h.hi_y0 = fuse_first->hi_y0;
+            h.lo_scale_x = fuse_first->lo_scale_x; h.lo_scale_y = fuse_first->lo_scale_y; h.lo_post_scale = fuse_first->lo_post_scale;
+            h.lo_zero_outside = fuse_first->lo_zero_outside; h.lo_vx0 = fuse_first->lo_vx0; h.lo_vy0 = fuse_first->lo_vy0;
+            h.lo_vx1 = fuse_first->lo_vx1; h.lo_vy1 = fuse_first->lo_vy1;
         }
         {
-            const double b = fused ? (4.0 + 4.0 + 2.0 + 8.0) * px : alg;  // C + conf + dL read, U0/U1 written
+            // C + conf + dL read, U0/U1 written (low-resolution maps: their bytes per view pixel, each row counted once)
+            const double lo_b = (fused && fuse_first->lo_conf) ? 6.0 * fuse_first->lo_scale_x * fuse_first->lo_scale_y : 6.0;
+            const double b = fused ? (4.0 + lo_b + 8.0) * px : alg;
             ProfScope ps(prof, fused ? K_PASS_H_FIRST : K_PASS_H, b, b, st);
             HIP_TRY(launch_wave_hpass(h, n_rhs, n_pairs, st));             // FGS.cpp:209
         }
@@ -475,6 +484,13 @@ struct adf_wls {
     hipStream_t side = nullptr;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     bool overlap = true;
+    // Down-scaled call whose first row pass interpolated the maps itself: the view-sized confidence map of
+    // getConfidenceMap() (DF.cpp:274) has not been materialised; adf_wls_get_confidence_* runs the float resize then.
+    struct LazyConf {
+        bool pending = false;
+        const float* clo = nullptr; int dW = 0, dH = 0; adf_rect rlo{0, 0, 0, 0}; Geom ghi{}; bool band_map = false; int n_pairs = 0;
+    } lazy_conf;
+    bool scaled_fuse = true; // ADF_SCALED_FUSE=0: the down-scaled path through the two resize kernels (A/B measurements)
     bool conf_band = true;   // ADF_CONF_BAND=0: the two-kernel confidence stage (A/B measurements)
     bool merge_small = true; // ADF_MERGE_SMALL=0: never the merged preparation launch (A/B measurements)
     size_t conf_lds_floor = 0; // ADF_CONF_LDS_FLOOR_KB: see ConfBandArgs::lds_floor (A/B measurements)
@@ -508,6 +524,7 @@ extern "C" int adf_wls_create(adf_wls_t** out, int use_confidence, int l, int r,
     }
     if (const char* e = getenv("ADF_NO_OVERLAP")) h->overlap = atoi(e) == 0;   // measurement knob
     if (const char* e = getenv("ADF_CONF_BAND")) h->conf_band = atoi(e) != 0;    // measurement knob
+    if (const char* e = getenv("ADF_SCALED_FUSE")) h->scaled_fuse = atoi(e) != 0;  // measurement knob
     if (const char* e = getenv("ADF_MERGE_SMALL")) h->merge_small = atoi(e) != 0;   // measurement knob
     if (const char* e = getenv("ADF_CONF_LDS_FLOOR_KB")) h->conf_lds_floor = (size_t)atoi(e) * 1024;
     *out = h;
@@ -599,6 +616,10 @@ static size_t wls_pair_ws_bytes(const Geom& g, bool conf, bool wave, bool disc_m
 // wls_filter_impl has forked to the side stream by then.
 struct ScaledStage;
 static int run_scaled_stage(const ScaledStage& s, hipStream_t st, Profiler* prof, int part);
+// fills `fuse` with the low-resolution form of the fused first row pass for the chunk starting at pair `first`, when the
+// stage asked for it; false = the resize kernels run
+static bool scaled_fuse_lo(const ScaledStage& s, int first, const Geom& g, WavePassArgs& fuse);
+static void scaled_note_lazy_conf(const ScaledStage& s);
 
 // conf_given: the down-scaled path (DF.cpp:274): the confidence kernels are skipped and dispR is not used; `scaled`
 // (may be null) fills h->conf with the view-sized confidence planes of all pairs and produces dispL itself.
@@ -636,6 +657,7 @@ static int wls_filter_impl(adf_wls_t* h, int n_pairs,
 
     DeviceScope ds(h->device);
     const Geom g = make_geom(W, H, roi.x, roi.y, roi.width, roi.height);
+    h->lazy_conf.pending = false;
     h->roi = roi; h->last_W = W; h->last_H = H; h->last_pairs = n_pairs;
     h->last_cpitch = g.cpitch; h->last_cx0 = g.cx0; h->last_path = 0;
 
@@ -758,11 +780,18 @@ static int wls_filter_impl(adf_wls_t* h, int n_pairs,
                     ProfScope ps(prof, K_FILL, 2.0 * (F - P), 2.0 * (F - P), st);
                     HIP_TRY(launch_outside(oa, n, st));                    // DF.cpp:284
                 }
-                if (scaled && first == 0 && ((rc = run_scaled_stage(*scaled, st, prof, 0)) || (rc = run_scaled_stage(*scaled, st, prof, 1)))) return rc;
+                const bool lo_fused = scaled && wave && scaled_fuse_lo(*scaled, first, g, fuse);
+                if (scaled && first == 0 && ((rc = run_scaled_stage(*scaled, st, prof, 0)) || (!lo_fused && (rc = run_scaled_stage(*scaled, st, prof, 1))))) return rc;
+                if (lo_fused) {
+                    // the first row pass taps the low-resolution maps itself: no resize launch, no view-sized planes
+                    h->last_path |= ADF_PATH_SCALED_FUSED;
+                    if (first == 0) scaled_note_lazy_conf(*scaled);
+                } else {
                 fuse.conf_in = confp; fuse.conf_frame = g.cframe; fuse.conf_pitch = g.cpitch; fuse.conf_x0 = g.cx0 + roi.x; fuse.conf_y0 = roi.y;
                 fuse.dl_in = dL; fuse.dl_stride = sL; fuse.dl_pair_stride = psL; fuse.dl_x0 = roi.x; fuse.dl_y0 = roi.y;
                 fuse.len = g.rw;
-                if (!(wave && wave_hpass_can_fuse(fuse))) {
+                }
+                if (!lo_fused && !(wave && wave_hpass_can_fuse(fuse))) {
                     fuse = WavePassArgs{};
                     PlainPrologueArgs pa{dL, sL, psL, ADF_16S, 1, 0, p.A0, g, orient_u2, confp, p.A1};
                     ProfScope ps(prof, K_PROLOGUE, 14.0 * P, 14.0 * P, st);
@@ -820,10 +849,10 @@ static int wls_filter_impl(adf_wls_t* h, int n_pairs,
                 }
             }
             if (fork_weights) HIP_TRY(hipStreamWaitEvent(st, h->ev_join, 0));
-            if (wave && fuse.conf_in) h->last_path |= ADF_PATH_FUSED_FIRST_PASS;
+            if (wave && (fuse.conf_in || fuse.lo_conf)) h->last_path |= ADF_PATH_FUSED_FIRST_PASS;
             FinalOut fo{EPI_WLS_CONF, o, sO, psO, roi.x, roi.y, 1, 0};
             rc = wave ? run_passes_wave(g, p, 2, (float)h->lambda, (float)h->atten, h->num_iter, fo, n, st, prof,
-                                        fuse.conf_in ? &fuse : nullptr)
+                                        (fuse.conf_in || fuse.lo_conf) ? &fuse : nullptr)
                       : run_passes_exact(g, p, 2, (float)h->lambda, (float)h->atten, h->num_iter, fo, n, st, prof);
             if (rc) return rc;                                             // DF.cpp:292-296
         } else {
@@ -862,7 +891,55 @@ struct ScaledStage {
     char* dhi; size_t dhi_bytes;
     float *cl, *cr, *clo;
     bool conf;
+    bool fuse_lo;   // the first row pass interpolates (decided by adf_wls_filter_scaled_device: dhi is not allocated then)
 };
+
+static bool scaled_band_map(const ScaledStage& s)
+{
+    return s.conf && s.h->conf_band &&
+           conf_band_fits(plain_conf_layout(make_geom(s.dW, s.dH, s.rlo.x, s.rlo.y, s.rlo.width, s.rlo.height)), s.h->disc_radius);
+}
+
+static void scaled_lo_args(const ScaledStage& s, int first, const Geom& g, WavePassArgs& f)
+{
+    const size_t lo = (size_t)s.dW * s.dH;
+    f = WavePassArgs{};
+    f.lo_conf = s.clo + (size_t)first * lo; f.lo_conf_stride = s.dW; f.lo_conf_pair = (ptrdiff_t)lo;
+    f.lo_dl = (const int16_t*)((const char*)s.dispL + (ptrdiff_t)first * s.psL); f.lo_dl_stride = s.sL; f.lo_dl_pair = s.psL;
+    f.lo_w = s.dW; f.lo_h = s.dH; f.hi_x0 = g.rx; f.hi_y0 = g.ry;
+    f.lo_scale_x = (double)s.dW / s.W; f.lo_scale_y = (double)s.dH / s.H; f.lo_post_scale = s.x_ratio;
+    if (scaled_band_map(s)) {
+        f.lo_zero_outside = 1; f.lo_vx0 = s.rlo.x; f.lo_vy0 = s.rlo.y; f.lo_vx1 = s.rlo.x + s.rlo.width; f.lo_vy1 = s.rlo.y + s.rlo.height;
+    }
+    f.len = g.rw;
+}
+
+static bool scaled_fuse_lo(const ScaledStage& s, int first, const Geom& g, WavePassArgs& fuse)
+{
+    if (!s.fuse_lo) return false;
+    scaled_lo_args(s, first, g, fuse);
+    return true;     // (adf_wls_filter_scaled_device has checked wave_hpass_can_fuse_lo on the same arguments)
+}
+
+static void scaled_note_lazy_conf(const ScaledStage& s)
+{
+    adf_wls::LazyConf& z = s.h->lazy_conf;
+    z.pending = true; z.clo = s.clo; z.dW = s.dW; z.dH = s.dH; z.rlo = s.rlo; z.ghi = s.ghi; z.band_map = scaled_band_map(s); z.n_pairs = s.n_pairs;
+}
+
+// cv::resize of the low-resolution confidence maps into the handle's view-sized planes (DF.cpp:274)
+static int resize_conf_planes(adf_wls_t* h, const float* clo, int dW, int dH, const adf_rect& rlo, const Geom& ghi, bool band_map,
+                              int n_pairs, hipStream_t st, Profiler* prof)
+{
+    const size_t lo = (size_t)dW * dH;
+    const double Fhi = (double)ghi.W * ghi.H * n_pairs;
+    ResizeArgs rc32{clo, (ptrdiff_t)dW * 4, (ptrdiff_t)(lo * 4), dW, dH, (float*)h->conf.p + ghi.cx0, (ptrdiff_t)ghi.cpitch * 4,
+                    (ptrdiff_t)(ghi.cframe * 4), ghi.W, ghi.H, (double)dW / ghi.W, (double)dH / ghi.H, 1.0f, 0};
+    if (band_map) { rc32.zero_outside = 1; rc32.vx0 = rlo.x; rc32.vy0 = rlo.y; rc32.vx1 = rlo.x + rlo.width; rc32.vy1 = rlo.y + rlo.height; }
+    ProfScope ps(prof, K_RESIZE, 4.0 * Fhi + 4.0 * (double)lo * n_pairs, 4.0 * Fhi + 4.0 * (double)lo * n_pairs, st);
+    HIP_TRY(launch_resize_linear(rc32, n_pairs, st));
+    return ADF_OK;
+}
 
 // part 0: the low-resolution confidence map; part 1: the two resizes.  Both are queued beside the weight kernel (after
 // its fork).  Measured at 64 x 4K views / 1080p maps: everything after the fork 13.8-14.1 / 13.8-14.0 ms per call (radius 2 / 5;
@@ -907,11 +984,8 @@ static int run_scaled_stage(const ScaledStage& s, hipStream_t st, Profiler* prof
     }
     if (part == 0) return ADF_OK;
     if (s.conf) {
-        ResizeArgs rc32{s.clo, (ptrdiff_t)dW * 4, (ptrdiff_t)(lo * 4), dW, dH, (float*)h->conf.p + s.ghi.cx0, (ptrdiff_t)s.ghi.cpitch * 4,
-                        (ptrdiff_t)(s.ghi.cframe * 4), W, H, (double)dW / W, (double)dH / H, 1.0f, 0};
-        if (band_map) { rc32.zero_outside = 1; rc32.vx0 = rlo.x; rc32.vy0 = rlo.y; rc32.vx1 = rlo.x + rlo.width; rc32.vy1 = rlo.y + rlo.height; }
-        ProfScope ps(prof, K_RESIZE, 4.0 * Fhi + 4.0 * (double)lo * n_pairs, 4.0 * Fhi + 4.0 * (double)lo * n_pairs, st);
-        HIP_TRY(launch_resize_linear(rc32, n_pairs, st));                  // DF.cpp:274
+        int rc = resize_conf_planes(h, s.clo, dW, dH, rlo, s.ghi, band_map, n_pairs, st, prof);   // DF.cpp:274
+        if (rc) return rc;
     }
     ResizeArgs r16{s.dispL, s.sL, s.psL, dW, dH, s.dhi, (ptrdiff_t)W * 2, (ptrdiff_t)s.dhi_bytes, W, H, (double)dW / W, (double)dH / H, s.x_ratio, 1};
     ProfScope ps(prof, K_RESIZE, 2.0 * Fhi + 2.0 * (double)lo * n_pairs, 2.0 * Fhi + 2.0 * (double)lo * n_pairs, st);
@@ -955,8 +1029,20 @@ extern "C" int adf_wls_filter_scaled_device(adf_wls_t* h, int n_pairs,
 
     DeviceScope ds(h->device);
     const size_t lo = (size_t)dW * dH, hi = (size_t)W * H;
-    // scratch: resized disparity (int16, view size) + low-resolution cL, cR, conf (float)
-    const size_t dhi_bytes = (hi * 2 + 255) / 256 * 256;
+    const Geom ghi = make_geom(W, H, rhi.x, rhi.y, rhi.width, rhi.height);   // the geometry wls_filter_impl will derive
+    // Can the first row pass interpolate the maps itself (fgs_wave_h.hip, FUSE_LO)?  Confidence mode on the wave solver,
+    // scale factors within the staging buffer's reach.  Then neither the resized disparity map nor -- until
+    // getConfidenceMap() asks for it -- the resized confidence map is ever written.
+    bool fuse_lo = false;
+    if (conf && h->scaled_fuse && h->solver == ADF_SOLVER_WAVE && wave_fits(ghi)) {
+        ScaledStage probe{h, n_pairs, dispL, sL, psL, dispR, sR, psR, dW, dH, W, H, rlo, ghi, resize_factor, x_ratio,
+                          nullptr, 0, nullptr, nullptr, reinterpret_cast<float*>(uintptr_t(256)), conf, true};
+        WavePassArgs f;
+        scaled_lo_args(probe, 0, ghi, f);
+        fuse_lo = wave_hpass_can_fuse_lo(f);
+    }
+    // scratch: resized disparity (int16, view size; not with fuse_lo) + low-resolution cL, cR, conf (float)
+    const size_t dhi_bytes = fuse_lo ? 0 : (hi * 2 + 255) / 256 * 256;
     const size_t need = (size_t)n_pairs * (dhi_bytes + (conf ? 3 * lo * sizeof(float) : 0));
     int rc = h->scaled.reserve(need, st);
     if (rc) return rc;
@@ -964,14 +1050,16 @@ extern "C" int adf_wls_filter_scaled_device(adf_wls_t* h, int n_pairs,
     float* cl = (float*)(dhi + (size_t)n_pairs * dhi_bytes);
     float* cr = cl + (size_t)n_pairs * lo;
     float* clo = cr + (size_t)n_pairs * lo;
-    const Geom ghi = make_geom(W, H, rhi.x, rhi.y, rhi.width, rhi.height);   // the geometry wls_filter_impl will derive
     if (conf && (rc = ensure_conf_planes(h, ghi, n_pairs, st))) return rc;
     ScaledStage stage{h, n_pairs, dispL, sL, psL, dispR, sR, psR, dW, dH, W, H, rlo, ghi, resize_factor, x_ratio,
-                      dhi, dhi_bytes, cl, cr, clo, conf};
+                      dhi, dhi_bytes, cl, cr, clo, conf, fuse_lo};
     // (without confidence the stage is the disparity resize alone; either way wls_filter_impl queues it after it has
     // forked the weight kernel, which needs the view only)
-    rc = wls_filter_impl(h, n_pairs, (const int16_t*)dhi, (ptrdiff_t)W * 2, (ptrdiff_t)dhi_bytes, view, sG, psG, gch, W, H,
-                         out, sO, psO, nullptr, 0, 0, &rhi, conf, st, &stage);
+    // (fuse_lo: wls_filter_impl never dereferences its dispL -- the caller's low-resolution map stands in, with its own strides)
+    rc = fuse_lo ? wls_filter_impl(h, n_pairs, dispL, (ptrdiff_t)W * 2, 0, view, sG, psG, gch, W, H,
+                                   out, sO, psO, nullptr, 0, 0, &rhi, conf, st, &stage)
+                 : wls_filter_impl(h, n_pairs, (const int16_t*)dhi, (ptrdiff_t)W * 2, (ptrdiff_t)dhi_bytes, view, sG, psG, gch, W, H,
+                                   out, sO, psO, nullptr, 0, 0, &rhi, conf, st, &stage);
     h->roi = rlo;                                                          // getROI(): valid_disp_ROI (DF.cpp:139)
     return rc;
 }
@@ -1069,6 +1157,14 @@ static int conf_copy(adf_wls_t* h, int pair, float* dst, ptrdiff_t stride, hipMe
         return fail(ADF_EBADARG, "no confidence map: filter() has not run with use_confidence");
     if (pair < 0 || pair >= h->last_pairs) return fail(ADF_EBADARG, "pair %d out of range [0,%d)", pair, h->last_pairs);
     if (stride < (ptrdiff_t)h->last_W * 4) return fail(ADF_ESIZE, "confidence stride smaller than a row");
+    if (h->lazy_conf.pending) {
+        // a down-scaled call whose first row pass interpolated the maps itself: resize the low-resolution confidence
+        // maps of the call now (DF.cpp:274; all pairs, one launch, outside the filter call), once
+        const adf_wls::LazyConf& z = h->lazy_conf;
+        int rc = resize_conf_planes(h, z.clo, z.dW, z.dH, z.rlo, z.ghi, z.band_map, z.n_pairs, st, nullptr);
+        if (rc) return rc;
+        h->lazy_conf.pending = false;
+    }
     const float* src = (const float*)h->conf.p + (size_t)pair * h->last_cpitch * h->last_H + h->last_cx0;
     HIP_TRY(hipMemcpy2DAsync(dst, stride, src, (size_t)h->last_cpitch * 4, (size_t)h->last_W * 4, h->last_H, kind, st));
     return ADF_OK;

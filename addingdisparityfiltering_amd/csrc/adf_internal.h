@@ -161,6 +161,17 @@ struct WavePassArgs {
     // sides are read as U1 = conf, U0 = conf * float(dL) from the confidence plane and the disparity map
     const float* conf_in; size_t conf_frame; int conf_pitch, conf_x0, conf_y0;
     const int16_t* dl_in; ptrdiff_t dl_stride, dl_pair_stride; int dl_x0, dl_y0;
+    // ... or, down-scaled path (DF.cpp:268-277 then 288-290), from the LOW-resolution maps: when lo_conf is set the
+    // pass interpolates the confidence map and the left disparity map itself (cv::resize INTER_LINEAR, tap for tap as
+    // resize_kernels.hip / the oracle's resize_linear_*; disparity saturated, multiplied by lo_post_scale and
+    // saturated again, DF.cpp:273), so neither view-sized plane is ever written.  ROI column j / row i of the pass is
+    // view pixel (hi_x0 + j, hi_y0 + i).  Confidence elements outside [lo_vx0, lo_vx1) x [lo_vy0, lo_vy1) read as
+    // zero when lo_zero_outside is set (the band kernel writes the maps' ROI only, DF.cpp:187-190).
+    const float* lo_conf; ptrdiff_t lo_conf_stride, lo_conf_pair;      // floats
+    const int16_t* lo_dl; ptrdiff_t lo_dl_stride, lo_dl_pair;          // bytes
+    int lo_w, lo_h, hi_x0, hi_y0;
+    double lo_scale_x, lo_scale_y; float lo_post_scale;
+    int lo_zero_outside, lo_vx0, lo_vy0, lo_vx1, lo_vy1;
     void* out; ptrdiff_t out_stride, out_pair_stride;
     int out_x0, out_y0, out_cn, out_c;
     int nscan, len, pitch;
@@ -191,6 +202,7 @@ hipError_t launch_wave_hpass(const WavePassArgs& a, int n_rhs, int n_pairs, hipS
 hipError_t launch_wave_vpass(const WavePassArgs& a, int n_rhs, int epilogue, int n_pairs, hipStream_t st);
 int wave_max_row_len();
 bool wave_hpass_can_fuse(const WavePassArgs& a);
+bool wave_hpass_can_fuse_lo(const WavePassArgs& a);   // the low-resolution form: scale / span limits of the LDS staging
 int wave_max_col_len();
 // largest depth-discontinuity radius the tile kernel supports (LDS bound)
 int max_disc_radius();

@@ -1,6 +1,8 @@
 // fgs_wave_h.hip -- horizontal pass of the on-chip partitioned solver (see fgs_wave_common.h).
 #include "fgs_wave_common.h"
 
+#include <algorithm>
+
 #ifndef ADF_H_TWO_WAVE_MAX
 #define ADF_H_TWO_WAVE_MAX 60   // longest chunk whose two-right-hand-side kernel fits two waves per SIMD
 #endif
@@ -23,12 +25,34 @@ using namespace wave;
 // stores, the chunk sweeps unchanged -- and meeting the other three times through LDS: the weight in front of chunk 64,
 // the left-end coefficients of chunk 64 for chunk 63's separator row, and the 128-row reduced system, which wave 0
 // solves (fgs_wave_common.h, reduced128).
-template <int M, int R, bool FUSED, int NW = 1>
+// FUSED == 2 (round 4): the down-scaled path's first pass -- the maps are LOW-resolution (the sample's default: matcher on
+// half-size views) and cv::resize is part of the prologue: the two source rows an output row taps (confidence and left
+// disparity) are staged in the wave's LDS buffer, coalesced, one half of the row's columns at a time, and every lane
+// interpolates its own columns from there with the exact tap arithmetic of resize_kernels.hip.  The two view-sized
+// planes the resize kernels wrote (6 B/px) and this pass read back (6 B/px) never exist.
+constexpr int FUSE_NONE = 0, FUSE_VIEW = 1, FUSE_LO = 2;
+
+// cv::resize's INTER_LINEAR tap of destination index d: source index s0 (and s0 + 1) with weights (1 - fx, fx);
+// borders clamp with weight (1, 0).  Same operations, same order as resize_linear_kernel / the oracle (host and device).
+__host__ __device__ __forceinline__ void lin_tap(int d, double scale, int sn, int& s0, float& fx)
+{
+    fx = (float)(((double)d + 0.5) * scale - 0.5);
+    s0 = (int)floorf(fx);
+    fx -= (float)s0;
+    if (s0 < 0) { fx = 0.0f; s0 = 0; }
+    if (s0 >= sn - 1) { fx = 0.0f; s0 = sn - 1; }
+}
+// floats per staged confidence row = shorts per staged disparity row: two of each fit the wave's M*256-byte buffer
+// (the shortest bucket's buffer is enlarged instead: its single float4 group per lane spans 256 columns)
+__host__ __device__ constexpr int lo_row_cap(int m) { return (((m * 64) / 3) & ~7) < 168 ? 168 : (((m * 64) / 3) & ~7); }
+__host__ __device__ constexpr int lo_stage_vec4(int m) { return 12 * lo_row_cap(m) > 256 * m ? (12 * lo_row_cap(m) + 15) / 16 : m * 16; }
+
+template <int M, int R, int FUSED, int NW = 1>
 __global__ void __launch_bounds__(64 * NW, (M > (NW == 2 ? 40 : ADF_H_TWO_WAVE_MAX) && R > 1) ? 1 : 2) wave_hpass_kernel(WavePassArgs a)
 {
     static_assert(M % 4 == 0 && M >= 4, "chunk length must be a multiple of 4");
     static_assert(NW == 1 || NW == 2, "one or two wavefronts per row");
-    __shared__ float4 stage_all[NW][M * 16];
+    __shared__ float4 stage_all[NW][FUSED == FUSE_LO ? lo_stage_vec4(M) : M * 16];
     __shared__ float xch[NW == 2 ? 5 : 1];              // c in front of chunk 64; GS0, GS1, PS, QS of chunk 64
     __shared__ float red[NW == 2 ? 5 : 1][NW == 2 ? 128 : 1];   // separator rows
     __shared__ float xsol[NW == 2 ? 2 : 1][NW == 2 ? 128 : 1];  // their solutions
@@ -58,7 +82,7 @@ __global__ void __launch_bounds__(64 * NW, (M > (NW == 2 ? 40 : ADF_H_TWO_WAVE_M
         const float4* s0 = reinterpret_cast<const float4*>(a.U0 + offU);
         // fused inputs (the launcher guarantees a 16-byte aligned conf row start and len >= 4)
         const float4* sF = nullptr; const char* sD = nullptr;
-        if (FUSED) {
+        if (FUSED == FUSE_VIEW) {
             sF = reinterpret_cast<const float4*>(a.conf_in + (size_t)blockIdx.y * a.conf_frame +
                                                  (size_t)(a.conf_y0 + blockIdx.x) * a.conf_pitch + a.conf_x0);
             sD = reinterpret_cast<const char*>(a.dl_in) + (ptrdiff_t)blockIdx.y * a.dl_pair_stride +
@@ -74,17 +98,177 @@ __global__ void __launch_bounds__(64 * NW, (M > (NW == 2 ? 40 : ADF_H_TWO_WAVE_M
         const int nfused = nfull + (rem ? 1 : 0);
         const unsigned dl_last = (unsigned)a.len * 2u - 8u;      // byte offset of the last whole vector (len >= 4)
         typedef short v4s_u __attribute__((ext_vector_type(4), aligned(2)));
-        short4 draw[FUSED ? M / 4 : 1];                          // fused: the row of the left disparity map
+        short4 draw[FUSED == FUSE_VIEW ? M / 4 : 1];             // fused: the row of the left disparity map
         // (an explicit branch per load: "cond ? *p : zero" would make the compiler select between
         // addresses and park the zero in scratch memory)
         // (idx: float4 of the row-major row; uidx: float4 of this wave's part of the interleaved pair row, 2 * M * 64 floats)
         const int u0 = PAIR ? 2 * v0 : v0;
+        if constexpr (FUSED == FUSE_LO) {
+            typedef float v4f __attribute__((ext_vector_type(4)));
+            typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));
+            typedef short s8u __attribute__((ext_vector_type(8), aligned(2)));
+            constexpr int KH = (MQ + 1) / 2;                      // float4 groups of the first half of the wave's columns
+            constexpr int CROW = lo_row_cap(M);
+            constexpr int TC4 = (CROW / 4 + 63) / 64, TD8 = (CROW / 8 + 63) / 64;
+            static_assert(12 * CROW <= 16 * lo_stage_vec4(M) && CROW % 8 == 0, "two confidence rows and two disparity rows fit the staging buffer");
+            const int sw = a.lo_w, sh = a.lo_h;
+            // the C row first: its loads are in flight while the low-resolution rows are fetched and staged
+#pragma unroll
+            for (int k = 0; k < MQ; k++) {
+                const int idx = v0 + 64 * k + lane;
+                tC[k] = make_float4(0.f, 0.f, 0.f, 0.f); t0[k] = tC[k]; t1[k] = tC[k];
+                if (idx < nvec) { const v4f q = __builtin_nontemporal_load(reinterpret_cast<const v4f*>(sC) + idx); tC[k] = make_float4(q.x, q.y, q.z, q.w); }
+            }
+            // rows (wave-uniform)
+            int sy; float fy;
+            {
+                const int dy = a.hi_y0 + (int)blockIdx.x;
+                fy = (float)(((double)dy + 0.5) * a.lo_scale_y - 0.5);
+                sy = (int)floorf(fy);
+                fy -= (float)sy;                                 // (rows clamp with their weights kept, like the resize kernel)
+            }
+            const float b0 = 1.0f - fy, b1 = fy;
+            const bool post_scaled = a.lo_post_scale != 1.0f;
+            int yr[2] = {min(max(sy, 0), sh - 1), min(max(sy + 1, 0), sh - 1)};
+            yr[0] = __builtin_amdgcn_readfirstlane(yr[0]); yr[1] = __builtin_amdgcn_readfirstlane(yr[1]);
+            const float* cbase = a.lo_conf + (ptrdiff_t)blockIdx.y * a.lo_conf_pair;
+            const char* dbase = reinterpret_cast<const char*>(a.lo_dl) + (ptrdiff_t)blockIdx.y * a.lo_dl_pair;
+            // columns of the two halves (wave-uniform): first source element and number of staged slots (the slot behind
+            // the last tap included: past the row's end it repeats the edge element, which carries weight 0)
+            int ss[2], ns[2];
+#pragma unroll
+            for (int hh = 0; hh < 2; hh++) {
+                const int cfirst = 64 * M * wv + 256 * (hh ? KH : 0);
+                const int clast = min(64 * M * wv + 256 * (hh ? MQ : KH), a.len) - 1;
+                int s_first = 0, s_last = -2; float f_;
+                if (clast >= cfirst) { lin_tap(a.hi_x0 + cfirst, a.lo_scale_x, sw, s_first, f_); lin_tap(a.hi_x0 + clast, a.lo_scale_x, sw, s_last, f_); }
+                ss[hh] = __builtin_amdgcn_readfirstlane(s_first);
+                ns[hh] = __builtin_amdgcn_readfirstlane(s_last + 2 - s_first);      // 0 for an empty half
+            }
+            // Per half: fetch the two source rows (coalesced: lane i takes source elements ss + 4i .. of the confidence
+            // rows, ss + 8i .. of the disparity rows; a vector that would cross the row's end is fetched element by
+            // element, clamped, which also fills the slots behind the row with the edge element), stage them, tap them.
+            // The second half's loads are issued when the first half has been staged, so they fly during its taps and
+            // only one half's raw rows occupy registers.
+            v4f rc[2][2][TC4]; s8u rd[2][2][TD8];
+            auto fetch = [&](int hh, v4f (&qc)[2][TC4], s8u (&qd)[2][TD8]) {
+#pragma unroll
+                for (int r = 0; r < 2; r++) {
+                    const float* crow = cbase + (ptrdiff_t)yr[r] * a.lo_conf_stride;
+                    const int16_t* drow = reinterpret_cast<const int16_t*>(dbase + (ptrdiff_t)yr[r] * a.lo_dl_stride);
+#pragma unroll
+                    for (int t = 0; t < TC4; t++) {
+                        const int e = ss[hh] + 4 * (64 * t + lane);
+                        qc[r][t] = v4f{0.f, 0.f, 0.f, 0.f};
+                        if (4 * (64 * t + lane) < ns[hh]) {
+                            if (e + 3 < sw) qc[r][t] = *reinterpret_cast<const f4u*>(crow + e);
+                            else {
+#pragma unroll
+                                for (int c = 0; c < 4; c++) qc[r][t][c] = crow[min(e + c, sw - 1)];
+                            }
+                        }
+                    }
+#pragma unroll
+                    for (int t = 0; t < TD8; t++) {
+                        const int e = ss[hh] + 8 * (64 * t + lane);
+                        qd[r][t] = s8u{0, 0, 0, 0, 0, 0, 0, 0};
+                        if (8 * (64 * t + lane) < ns[hh]) {
+                            if (e + 7 < sw) qd[r][t] = *reinterpret_cast<const s8u*>(drow + e);
+                            else {
+#pragma unroll
+                                for (int c = 0; c < 8; c++) qd[r][t][c] = drow[min(e + c, sw - 1)];
+                            }
+                        }
+                    }
+                }
+            };
+            float* Lf = reinterpret_cast<float*>(stage);
+            const short* Ls = reinterpret_cast<const short*>(stage) + 4 * CROW;      // behind the two confidence rows
+            v4f* Lf4 = reinterpret_cast<v4f*>(stage);
+            typedef short s8a __attribute__((ext_vector_type(8)));
+            s8a* Ls8 = reinterpret_cast<s8a*>(stage) + CROW / 2;
+            auto put = [&](int hh, const v4f (&qc)[2][TC4], const s8u (&qd)[2][TD8]) {
+#pragma unroll
+                for (int r = 0; r < 2; r++) {
+                    const bool rin = !a.lo_zero_outside || (yr[r] >= a.lo_vy0 && yr[r] < a.lo_vy1);
+#pragma unroll
+                    for (int t = 0; t < TC4; t++) {
+                        const int i4 = 64 * t + lane, e = ss[hh] + 4 * i4;
+                        v4f q = qc[r][t];
+                        if (a.lo_zero_outside) {
+#pragma unroll
+                            for (int c = 0; c < 4; c++) {
+                                const int ec = min(e + c, sw - 1);
+                                if (!(rin && ec >= a.lo_vx0 && ec < a.lo_vx1)) q[c] = 0.0f;
+                            }
+                        }
+                        if (4 * i4 < CROW) Lf4[r * (CROW / 4) + i4] = q;
+                    }
+#pragma unroll
+                    for (int t = 0; t < TD8; t++) {
+                        const int i8 = 64 * t + lane;
+                        const s8u q = qd[r][t];
+                        if (8 * i8 < CROW) Ls8[r * (CROW / 8) + i8] = s8a{q[0], q[1], q[2], q[3], q[4], q[5], q[6], q[7]};
+                    }
+                }
+            };
+            fetch(0, rc[0], rd[0]);
+#pragma unroll
+            for (int hh = 0; hh < 2; hh++) {
+                put(hh, rc[hh], rd[hh]);
+                __syncthreads();
+                if (hh == 0) {
+                    asm volatile("" ::: "memory");               // (the next half's loads: not before this half is staged)
+                    fetch(1, rc[1], rd[1]);
+                }
+#pragma unroll
+                for (int k = (hh ? KH : 0); k < (hh ? MQ : KH); k++) {
+                    // (opaque: the taps depend on the lane index only, and the compiler would otherwise form all of them
+                    // -- eight registers per float4 -- while the loads are in flight, spilling the row)
+                    int lane_t = lane;
+                    asm volatile("" : "+v"(lane_t) :: "memory");
+                    const int idx = v0 + 64 * k + lane_t;
+                    float cv[4], dv[4];
+#pragma unroll
+                    for (int c = 0; c < 4; c++) {
+                        const int col = 4 * idx + c;
+                        int s0; float fx;
+                        lin_tap(a.hi_x0 + min(col, a.len - 1), a.lo_scale_x, sw, s0, fx);
+                        const int sl = min(max(s0 - ss[hh], 0), CROW - 2);          // (in range by construction; the clamp keeps a bug from reading other waves' LDS)
+                        const float a0 = 1.0f - fx, a1 = fx;
+                        const float h0 = Lf[sl] * a0 + Lf[sl + 1] * a1;
+                        const float h1 = Lf[CROW + sl] * a0 + Lf[CROW + sl + 1] * a1;
+                        const float g0 = (float)Ls[sl] * a0 + (float)Ls[sl + 1] * a1;
+                        const float g1 = (float)Ls[CROW + sl] * a0 + (float)Ls[CROW + sl + 1] * a1;
+                        const float conf = h0 * b0 + h1 * b1;                       // DF.cpp:274
+                        // saturate_cast<short> twice (DF.cpp:272, then x_ratio, :273) without branches: both arguments are
+                        // finite and far inside the int range here (a convex combination of int16 values; that times the
+                        // size ratio), so sat16's guard for NaN / out-of-int-range cannot fire -- and a branch per column
+                        // would let the compiler sink every column's arithmetic behind the last one's (registers)
+                        const float q1 = fminf(fmaxf(rintf(g0 * b0 + g1 * b1), -32768.0f), 32767.0f);
+                        const float q2 = fminf(fmaxf(rintf(q1 * a.lo_post_scale), -32768.0f), 32767.0f);
+                        const float q = post_scaled ? q2 : q1;
+                        const bool on = col < a.len;
+                        cv[c] = on ? conf : 0.0f;
+                        dv[c] = on ? q : 0.0f;
+                    }
+                    t1[k] = make_float4(cv[0], cv[1], cv[2], cv[3]);               // U1 = conf, U0 = conf * float(dL)  (DF.cpp:288-290)
+                    t0[k] = make_float4(cv[0] * dv[0], cv[1] * dv[1], cv[2] * dv[2], cv[3] * dv[3]);
+                    // (pinned here: nothing reads t0 / t1 before the transposes, and the compiler would sink the arithmetic
+                    // down to them, holding sixteen staged values per column in registers all the way)
+                    asm volatile("" : "+v"(t1[k].x), "+v"(t1[k].y), "+v"(t1[k].z), "+v"(t1[k].w),
+                                      "+v"(t0[k].x), "+v"(t0[k].y), "+v"(t0[k].z), "+v"(t0[k].w));
+                    __builtin_amdgcn_sched_barrier(0);           // one float4 of columns at a time (register pressure)
+                }
+                __syncthreads();
+            }
+        } else {
 #pragma unroll
         for (int k = 0; k < M / 4; k++) {
             const int idx = v0 + 64 * k + lane, uidx = u0 + 64 * k + lane;
             tC[k] = make_float4(0.f, 0.f, 0.f, 0.f); t0[k] = tC[k]; t1[k] = tC[k];
-            if (FUSED) draw[k] = make_short4(0, 0, 0, 0);
-            if (FUSED) {
+            if (FUSED == FUSE_VIEW) draw[k] = make_short4(0, 0, 0, 0);
+            if (FUSED == FUSE_VIEW) {
                 typedef float v4f __attribute__((ext_vector_type(4)));
                 if (idx < nvec) { const v4f q = __builtin_nontemporal_load(reinterpret_cast<const v4f*>(sC) + idx); tC[k] = make_float4(q.x, q.y, q.z, q.w); }
                 // loads only: the products conf*float(dL) wait for the second loop, or every iteration would
@@ -104,7 +288,8 @@ __global__ void __launch_bounds__(64 * NW, (M > (NW == 2 ? 40 : ADF_H_TWO_WAVE_M
                 if (PAIR && uidx + 64 * MQ < nvecU) { const v4f q = __builtin_nontemporal_load(reinterpret_cast<const v4f*>(s0) + ADF_PIDX(uidx + 64 * MQ)); t1[k] = make_float4(q.x, q.y, q.z, q.w); }
             }
         }
-        if (FUSED) {                                             // U1 = conf, U0 = conf * float(dL)  (DF.cpp:288-290)
+        }
+        if (FUSED == FUSE_VIEW) {                                // U1 = conf, U0 = conf * float(dL)  (DF.cpp:288-290)
             const int tl = nfull - v0;                           // the partial vector, counted from this wave's first
             const int ktail = (rem && tl >= 0 && tl < 16 * M) ? (tl >> 6) : -1;   // wave-uniform: the one k that holds it
 #pragma unroll
@@ -156,7 +341,7 @@ __global__ void __launch_bounds__(64 * NW, (M > (NW == 2 ? 40 : ADF_H_TWO_WAVE_M
         __syncthreads();                                                                  \
     }
     ADF_TRANSPOSE_IN(tC, c[0], a.lambda)
-    if (PAIR && !FUSED) {
+    if (PAIR && FUSED == FUSE_NONE) {
         ADF_PAIR_IN(t0, 0)
         ADF_PAIR_IN(t1, 1)
     } else {
@@ -252,12 +437,27 @@ template <int M, int NW = 1>
 hipError_t launch_h(const WavePassArgs& a, int n_rhs, int n_pairs, hipStream_t st)
 {
     dim3 grid(a.nscan, n_pairs), block(64 * NW);
-    if (a.conf_in) {
+    if (a.lo_conf) {
         if (n_rhs != 2) return hipErrorInvalidValue;
-        hipLaunchKernelGGL((wave_hpass_kernel<M, 2, true, NW>), grid, block, 0, st, a);
-    } else if (n_rhs == 2) hipLaunchKernelGGL((wave_hpass_kernel<M, 2, false, NW>), grid, block, 0, st, a);
-    else hipLaunchKernelGGL((wave_hpass_kernel<M, 1, false, NW>), grid, block, 0, st, a);
+        hipLaunchKernelGGL((wave_hpass_kernel<M, 2, FUSE_LO, NW>), grid, block, 0, st, a);
+    } else if (a.conf_in) {
+        if (n_rhs != 2) return hipErrorInvalidValue;
+        hipLaunchKernelGGL((wave_hpass_kernel<M, 2, FUSE_VIEW, NW>), grid, block, 0, st, a);
+    } else if (n_rhs == 2) hipLaunchKernelGGL((wave_hpass_kernel<M, 2, FUSE_NONE, NW>), grid, block, 0, st, a);
+    else hipLaunchKernelGGL((wave_hpass_kernel<M, 1, FUSE_NONE, NW>), grid, block, 0, st, a);
     return hipGetLastError();
+}
+
+// chunk length / wavefronts per row the launcher picks for a row of `len` elements
+void pick_row_bucket(int len, int& m, int& nw)
+{
+    if (len > 64 * 64) {
+        const int q = (len + 127) / 128;
+        nw = 2; m = q <= 40 ? 40 : q <= 48 ? 48 : q <= 56 ? 56 : q <= 60 ? 60 : 64;
+        return;
+    }
+    const int q = (len + 63) / 64;
+    nw = 1; m = q <= 4 ? 4 : q <= 8 ? 8 : q <= 16 ? 16 : q <= 20 ? 20 : q <= 28 ? 28 : q <= 40 ? 40 : q <= 56 ? 56 : q <= 60 ? 60 : 64;
 }
 
 } // namespace
@@ -277,28 +477,58 @@ bool wave_hpass_can_fuse(const WavePassArgs& a)
     return true;
 }
 
+// The low-resolution form stages, per wavefront and per half of its columns, the source elements its taps touch plus
+// one: that span must fit lo_row_cap(M) slots (scale factors up to about 0.66 do, whatever the bucket), the strides
+// must keep rows 4-byte / 2-byte aligned.  The same tap function runs here and in the kernel.
+bool wave_hpass_can_fuse_lo(const WavePassArgs& a)
+{
+    if (!a.lo_conf || !a.lo_dl || a.lo_w < 2 || a.lo_h < 1 || a.len < 2 || a.len > wave_max_row_len()) return false;
+    if ((reinterpret_cast<uintptr_t>(a.lo_conf) & 3u) != 0 || (reinterpret_cast<uintptr_t>(a.lo_dl) & 1u) != 0) return false;
+    if (a.lo_dl_stride % 2 != 0 || a.lo_dl_pair % 2 != 0) return false;
+    if (!(a.lo_scale_x > 0.0 && a.lo_scale_y > 0.0) || a.hi_x0 < 0 || a.hi_y0 < 0) return false;
+    int m, nw;
+    pick_row_bucket(a.len, m, nw);
+    const int mq = m / 4, kh = (mq + 1) / 2, cap = lo_row_cap(m);
+    for (int wv = 0; wv < nw; wv++)
+        for (int hh = 0; hh < 2; hh++) {
+            const int cfirst = 64 * m * wv + 256 * (hh ? kh : 0);
+            const int clast = std::min(64 * m * wv + 256 * (hh ? mq : kh), a.len) - 1;
+            if (clast < cfirst) continue;
+            int s_first, s_last; float f_;
+            lin_tap(a.hi_x0 + cfirst, a.lo_scale_x, a.lo_w, s_first, f_);
+            lin_tap(a.hi_x0 + clast, a.lo_scale_x, a.lo_w, s_last, f_);
+            if (s_last + 2 - s_first > cap) return false;
+        }
+    return true;
+}
+
 hipError_t launch_wave_hpass(const WavePassArgs& a, int n_rhs, int n_pairs, hipStream_t st)
 {
     if (a.len < 2 || a.len > wave_max_row_len() || a.pitch % 64 != 0 || a.pitch < a.len) return hipErrorInvalidValue;
-    if (a.conf_in && !wave_hpass_can_fuse(a)) return hipErrorInvalidValue;
-    if (a.len > 64 * 64) {   // wider than 4096 columns: two wavefronts per row
-        const int m = (a.len + 127) / 128;
-        if (m <= 40) return launch_h<40, 2>(a, n_rhs, n_pairs, st);
-        if (m <= 48) return launch_h<48, 2>(a, n_rhs, n_pairs, st);
-        if (m <= 56) return launch_h<56, 2>(a, n_rhs, n_pairs, st);
-        if (m <= 60) return launch_h<60, 2>(a, n_rhs, n_pairs, st);   // 7680 columns: a full 8K row
-        return launch_h<64, 2>(a, n_rhs, n_pairs, st);
+    if (a.lo_conf && !wave_hpass_can_fuse_lo(a)) return hipErrorInvalidValue;
+    if (!a.lo_conf && a.conf_in && !wave_hpass_can_fuse(a)) return hipErrorInvalidValue;
+    int m, nw;
+    pick_row_bucket(a.len, m, nw);
+    if (nw == 2) {           // wider than 4096 columns: two wavefronts per row
+        switch (m) {
+        case 40: return launch_h<40, 2>(a, n_rhs, n_pairs, st);
+        case 48: return launch_h<48, 2>(a, n_rhs, n_pairs, st);
+        case 56: return launch_h<56, 2>(a, n_rhs, n_pairs, st);
+        case 60: return launch_h<60, 2>(a, n_rhs, n_pairs, st);   // 7680 columns: a full 8K row
+        default: return launch_h<64, 2>(a, n_rhs, n_pairs, st);
+        }
     }
-    const int m = (a.len + 63) / 64;
-    if (m <= 4) return launch_h<4>(a, n_rhs, n_pairs, st);
-    if (m <= 8) return launch_h<8>(a, n_rhs, n_pairs, st);
-    if (m <= 16) return launch_h<16>(a, n_rhs, n_pairs, st);
-    if (m <= 20) return launch_h<20>(a, n_rhs, n_pairs, st);
-    if (m <= 28) return launch_h<28>(a, n_rhs, n_pairs, st);
-    if (m <= 40) return launch_h<40>(a, n_rhs, n_pairs, st);
-    if (m <= 56) return launch_h<56>(a, n_rhs, n_pairs, st);
-    if (m <= 60) return launch_h<60>(a, n_rhs, n_pairs, st);   // 3840 columns: a full 4K row
-    return launch_h<64>(a, n_rhs, n_pairs, st);
+    switch (m) {
+    case 4: return launch_h<4>(a, n_rhs, n_pairs, st);
+    case 8: return launch_h<8>(a, n_rhs, n_pairs, st);
+    case 16: return launch_h<16>(a, n_rhs, n_pairs, st);
+    case 20: return launch_h<20>(a, n_rhs, n_pairs, st);
+    case 28: return launch_h<28>(a, n_rhs, n_pairs, st);
+    case 40: return launch_h<40>(a, n_rhs, n_pairs, st);
+    case 56: return launch_h<56>(a, n_rhs, n_pairs, st);
+    case 60: return launch_h<60>(a, n_rhs, n_pairs, st);       // 3840 columns: a full 4K row
+    default: return launch_h<64>(a, n_rhs, n_pairs, st);
+    }
 }
 
 } // namespace adf

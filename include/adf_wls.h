@@ -122,6 +122,9 @@ int adf_wls_get_last_solver(const adf_wls_t* h, int* solver);
 #define ADF_PATH_CONF_BAND 1
 #define ADF_PATH_FUSED_FIRST_PASS 2
 #define ADF_PATH_MERGED_PREP 4       /* weights + confidence + fill ran as ONE launch (small calls) */
+#define ADF_PATH_SCALED_FUSED 8      /* down-scaled call: the first row pass interpolated the low-resolution maps itself
+                                        (no resize launch); the view-sized confidence map is produced on demand by
+                                        adf_wls_get_confidence_* */
 int adf_wls_get_last_path(const adf_wls_t* h, int* path_flags);
 
 /* DisparityFilter::filter (DF.hpp:75, DF.cpp:219-298) on a batch of n_pairs

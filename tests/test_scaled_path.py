@@ -129,3 +129,129 @@ def test_scaled_path_other_ratios(adf, oracle, sizes):
     got2 = f.filter(dl, view, None, dr, roi)
     d = np.abs(got2.astype(np.int64) - exp)
     assert d.max() <= 1 and d.mean() <= 1 / 256
+
+
+# ---------------------------------------------------------------------------------------------
+# Round 4: the first row pass interpolates the low-resolution maps itself (fgs_wave_h.hip, FUSE_LO); the resized
+# confidence map is materialised on demand.  The prologue is exact arithmetic, so the SAME solver fed by the fused
+# prologue and by the two resize kernels must give bit-identical maps -- a sharper statement than the wave solver's
+# 1-LSB distance from the oracle.
+# ---------------------------------------------------------------------------------------------
+def _filter_with_env(adf, env, fn):
+    import os
+
+    old = {k: os.environ.get(k) for k in env}
+    os.environ.update(env)
+    try:
+        f = adf.createDisparityWLSFilterGeneric(True)      # the knobs are read when the handle is made
+    finally:
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+    return fn(f)
+
+
+def _scaled_inputs(w, h, mw, mh, ch, seed, roi_x=None):
+    view = synthetic.make_artificial_example(w, h, ch, seed=seed)[0]
+    _, dl, dr, roi = synthetic.make_artificial_example(mw, mh, 1, seed=seed + 1)
+    x = min(roi[0], mw // 4) if roi_x is None else roi_x
+    return view, dl, dr, (x, 0, mw - x, mh)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", [
+    # view, maps, channels, ROI of the maps (None = from the example), radius
+    ((320, 240), (160, 120), 3, None, 5),
+    ((320, 240), (160, 120), 1, (37, 5, 101, 97), 2),          # odd ROI origin and size (partial last vector)
+    ((321, 243), (160, 121), 3, None, 2),                       # scale just under one half, odd sizes
+    ((320, 240), (107, 80), 3, None, 5),                        # a third
+    ((320, 240), (192, 144), 3, None, 2),                       # 0.6: still inside the staging buffer's reach
+    ((1283, 97), (640, 48), 3, (3, 1, 630, 45), 2),            # wide and flat
+    ((64, 48), (32, 24), 3, None, 2),                           # tiny: the shortest chunk bucket
+    ((640, 360), (320, 180), 3, None, 9),                       # radius 9: the two-kernel confidence stage (no zero window)
+    ((2600, 64), (1300, 32), 1, None, 2),                       # chunk bucket 40 / 56 boundary region
+    ((3840, 270), (1920, 135), 3, (128, 0, 1792, 135), 2),      # BASELINE config 3's row length (bucket 56)
+    ((3840, 136), (1920, 68), 3, (0, 0, 1920, 68), 5),          # a full 4K row (bucket 60)
+    ((4200, 72), (2100, 36), 1, None, 2),                       # more than 4096 columns: two wavefronts per row
+    ((7680, 80), (3840, 40), 3, (0, 0, 3840, 40), 2),           # a full 8K row
+])
+def test_fused_scaled_first_pass_equals_the_resize_kernels(adf, oracle, case):
+    (w, h), (mw, mh), ch, roi, radius = case
+    view, dl, dr, r0 = _scaled_inputs(w, h, mw, mh, ch, seed=w + mh + radius)
+    roi = r0 if roi is None else roi
+
+    def run(f):
+        f.setSolver(adf.SOLVER_WAVE); f.setSigmaColor(1.5); f.setDepthDiscontinuityRadius(radius)
+        out = f.filter(dl, view, None, dr, roi)
+        path = f.getLastPath()
+        return out, path, f.getConfidenceMap(), f.getLastSolver()
+
+    fused, pf, cf, sf = _filter_with_env(adf, {"ADF_SCALED_FUSE": "1"}, run)
+    plain, pp, cp, sp = _filter_with_env(adf, {"ADF_SCALED_FUSE": "0"}, run)
+    assert sf == sp == adf.SOLVER_WAVE
+    assert pf & adf.PATH_SCALED_FUSED and pf & adf.PATH_FUSED_FIRST_PASS, pf
+    assert not (pp & adf.PATH_SCALED_FUSED), pp
+    assert np.array_equal(fused, plain)                          # bit for bit: same solver, exact prologue
+    assert np.array_equal(cf, cp)                                # the confidence map made on demand == the one made in the call
+    if w * h <= 700000:
+        p = oracle.default_params(sigma_color=1.5, threads=8, disc_radius=radius)
+        exp, exp_conf = oracle.wls_filter_scaled(dl, view, dr, roi, p)
+        assert np.array_equal(cf, exp_conf)
+        d = np.abs(fused.astype(np.int64) - exp)
+        assert d.max() <= 1 and d.mean() <= 1 / 256
+
+
+@pytest.mark.gpu
+def test_fused_scaled_falls_back_beyond_the_staging_reach(adf, oracle):
+    """0.7 across: the taps of half a row no longer fit the wave's staging buffer -> the resize kernels run."""
+    view, dl, dr, roi = _scaled_inputs(320, 240, 224, 168, 3, seed=9)
+    f = adf.createDisparityWLSFilterGeneric(True)
+    f.setSolver(adf.SOLVER_WAVE); f.setSigmaColor(1.5)
+    got = f.filter(dl, view, None, dr, roi)
+    assert not (f.getLastPath() & adf.PATH_SCALED_FUSED)
+    exp, exp_conf = oracle.wls_filter_scaled(dl, view, dr, roi, oracle.default_params(sigma_color=1.5, threads=8))
+    assert np.array_equal(f.getConfidenceMap(), exp_conf)
+    d = np.abs(got.astype(np.int64) - exp)
+    assert d.max() <= 1 and d.mean() <= 1 / 256
+
+
+@pytest.mark.gpu
+def test_fused_scaled_batch_chunks_and_lazy_confidence(adf, oracle):
+    """A device batch cut into workspace chunks (every chunk's first pass taps its own pairs' maps); the confidence maps
+    of ALL pairs appear on demand, once, and a later same-size call or a later scaled call replaces them."""
+    import os
+
+    import torch
+
+    n, w, h = 5, 512, 256
+    ex = [_scaled_inputs(w, h, w // 2, h // 2, 3, seed=200 + 3 * k) for k in range(n)]
+    roi = ex[0][3]
+    view = np.stack([e[0] for e in ex]); dl = np.stack([e[1] for e in ex]); dr = np.stack([e[2] for e in ex])
+    dev = torch.device("cuda:0")
+    tv, tl, tr = (torch.from_numpy(a).to(dev) for a in (view, dl, dr))
+
+    def run(f):
+        f.setSolver(adf.SOLVER_WAVE); f.setSigmaColor(1.5)
+        out = f.filter(tl, tv, None, tr, roi)
+        return f, out.cpu().numpy(), f.getLastPath()
+
+    f1, whole, p1 = _filter_with_env(adf, {}, run)
+    per_pair = f1.workspaceBytes()
+    f2, chunked, p2 = _filter_with_env(adf, {"ADF_WS_LIMIT_GB": "%.6f" % (2.2 * (per_pair / n) / 2 ** 30)}, run)
+    f3, plain, p3 = _filter_with_env(adf, {"ADF_SCALED_FUSE": "0"}, run)
+    assert p1 & adf.PATH_SCALED_FUSED and p2 & adf.PATH_SCALED_FUSED and not (p3 & adf.PATH_SCALED_FUSED)
+    assert np.array_equal(whole, plain) and np.array_equal(chunked, plain)
+    confs = f2.getConfidenceMap().cpu().numpy()
+    assert np.array_equal(confs, f3.getConfidenceMap().cpu().numpy())
+    for k in (0, n - 1):
+        exp, exp_conf = oracle.wls_filter_scaled(dl[k], view[k], dr[k], roi, oracle.default_params(sigma_color=1.5, threads=8))
+        assert np.array_equal(confs[k], exp_conf)
+        assert np.array_equal(f1.getConfidenceMap(k).cpu().numpy(), exp_conf)      # one pair on demand
+    # a same-size call afterwards: its own confidence map, nothing pending from the scaled call
+    v1, l1, r1, roi1 = synthetic.make_artificial_example(w, h, 3, seed=77)
+    out1 = f1.filter(l1, v1, None, r1, roi1)
+    e1, c1 = oracle.wls_filter(l1, v1, r1, roi1, oracle.default_params(sigma_color=1.5, threads=8))
+    assert np.array_equal(f1.getConfidenceMap(), c1)
+    assert np.abs(out1.astype(np.int64) - e1).max() <= 1
