@@ -413,7 +413,7 @@ static int run_passes_wave(const Geom& g, const SolvePlanes& p, int n_rhs, float
             h.lo_w = fuse_first->lo_w; h.lo_h = fuse_first->lo_h; h.hi_x0 = fuse_first->hi_x0; h.hi_y0 = fuse_first->hi_y0;
             h.lo_scale_x = fuse_first->lo_scale_x; h.lo_scale_y = fuse_first->lo_scale_y; h.lo_post_scale = fuse_first->lo_post_scale;
             h.lo_zero_outside = fuse_first->lo_zero_outside; h.lo_vx0 = fuse_first->lo_vx0; h.lo_vy0 = fuse_first->lo_vy0;
-            h.lo_vx1 = fuse_first->lo_vx1; h.lo_vy1 = fuse_first->lo_vy1;
+            h.lo_vx1 = fuse_first->lo_vx1; h.lo_vy1 = fuse_first->lo_vy1; h.lo_taps = fuse_first->lo_taps;
         }
         {
             // C + conf + dL read, U0/U1 written (low-resolution maps: their bytes per view pixel, each row counted once)
@@ -892,6 +892,7 @@ struct ScaledStage {
     float *cl, *cr, *clo;
     bool conf;
     bool fuse_lo;   // the first row pass interpolates (decided by adf_wls_filter_scaled_device: dhi is not allocated then)
+    float* taps;    // ... with this scratch for the columns' source coordinates
 };
 
 static bool scaled_band_map(const ScaledStage& s)
@@ -911,7 +912,7 @@ static void scaled_lo_args(const ScaledStage& s, int first, const Geom& g, WaveP
     if (scaled_band_map(s)) {
         f.lo_zero_outside = 1; f.lo_vx0 = s.rlo.x; f.lo_vy0 = s.rlo.y; f.lo_vx1 = s.rlo.x + s.rlo.width; f.lo_vy1 = s.rlo.y + s.rlo.height;
     }
-    f.len = g.rw;
+    f.len = g.rw; f.lo_taps = s.taps;
 }
 
 static bool scaled_fuse_lo(const ScaledStage& s, int first, const Geom& g, WavePassArgs& fuse)
@@ -1036,23 +1037,25 @@ extern "C" int adf_wls_filter_scaled_device(adf_wls_t* h, int n_pairs,
     bool fuse_lo = false;
     if (conf && h->scaled_fuse && h->solver == ADF_SOLVER_WAVE && wave_fits(ghi)) {
         ScaledStage probe{h, n_pairs, dispL, sL, psL, dispR, sR, psR, dW, dH, W, H, rlo, ghi, resize_factor, x_ratio,
-                          nullptr, 0, nullptr, nullptr, reinterpret_cast<float*>(uintptr_t(256)), conf, true};
+                          nullptr, 0, nullptr, nullptr, reinterpret_cast<float*>(uintptr_t(256)), conf, true, nullptr};
         WavePassArgs f;
         scaled_lo_args(probe, 0, ghi, f);
         fuse_lo = wave_hpass_can_fuse_lo(f);
     }
     // scratch: resized disparity (int16, view size; not with fuse_lo) + low-resolution cL, cR, conf (float)
     const size_t dhi_bytes = fuse_lo ? 0 : (hi * 2 + 255) / 256 * 256;
-    const size_t need = (size_t)n_pairs * (dhi_bytes + (conf ? 3 * lo * sizeof(float) : 0));
+    const size_t maps_bytes = ((size_t)n_pairs * (dhi_bytes + (conf ? 3 * lo * sizeof(float) : 0)) + 255) / 256 * 256;
+    const size_t need = maps_bytes + (fuse_lo ? 2 * ((size_t)rhi.width + 4) * sizeof(float) : 0);   // + the columns' taps
     int rc = h->scaled.reserve(need, st);
     if (rc) return rc;
     char* dhi = (char*)h->scaled.p;
     float* cl = (float*)(dhi + (size_t)n_pairs * dhi_bytes);
     float* cr = cl + (size_t)n_pairs * lo;
     float* clo = cr + (size_t)n_pairs * lo;
+    float* taps = fuse_lo ? (float*)((char*)h->scaled.p + maps_bytes) : nullptr;
     if (conf && (rc = ensure_conf_planes(h, ghi, n_pairs, st))) return rc;
     ScaledStage stage{h, n_pairs, dispL, sL, psL, dispR, sR, psR, dW, dH, W, H, rlo, ghi, resize_factor, x_ratio,
-                      dhi, dhi_bytes, cl, cr, clo, conf, fuse_lo};
+                      dhi, dhi_bytes, cl, cr, clo, conf, fuse_lo, taps};
     // (without confidence the stage is the disparity resize alone; either way wls_filter_impl queues it after it has
     // forked the weight kernel, which needs the view only)
     // (fuse_lo: wls_filter_impl never dereferences its dispL -- the caller's low-resolution map stands in, with its own strides)

@@ -172,6 +172,7 @@ struct WavePassArgs {
     int lo_w, lo_h, hi_x0, hi_y0;
     double lo_scale_x, lo_scale_y; float lo_post_scale;
     int lo_zero_outside, lo_vx0, lo_vy0, lo_vx1, lo_vy1;
+    float* lo_taps;   // scratch, 4*ceil(len/4) floats, 16-byte aligned: the launcher fills it with the columns' taps (s0 + fx)
     void* out; ptrdiff_t out_stride, out_pair_stride;
     int out_x0, out_y0, out_cn, out_c;
     int nscan, len, pitch;

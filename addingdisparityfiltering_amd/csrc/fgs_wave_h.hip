@@ -3,6 +3,16 @@
 
 #include <algorithm>
 
+// A/B knobs of the low-resolution fused prologue (tools/ab_lo.sh)
+#ifndef ADF_LO_UMASK
+#define ADF_LO_UMASK 1      // end-of-row masks only in the float4 group that can reach the row's end (wave-uniform branch)
+#endif
+#ifndef ADF_LO_NEEDMASK
+#define ADF_LO_NEEDMASK 1   // zero-window masks only where a half's staged span leaves the window (wave-uniform branch)
+#endif
+#ifndef ADF_LO_TAPS_EARLY
+#define ADF_LO_TAPS_EARLY 2 // tap table entries requested: 0 = per half, when it has been staged; 1 = per half, before; 2 = all, with the row's first loads
+#endif
 #ifndef ADF_H_TWO_WAVE_MAX
 #define ADF_H_TWO_WAVE_MAX 60   // longest chunk whose two-right-hand-side kernel fits two waves per SIMD
 #endif
@@ -41,6 +51,19 @@ __host__ __device__ __forceinline__ void lin_tap(int d, double scale, int sn, in
     fx -= (float)s0;
     if (s0 < 0) { fx = 0.0f; s0 = 0; }
     if (s0 >= sn - 1) { fx = 0.0f; s0 = sn - 1; }
+}
+// The taps of a call's ROI columns are the same for every row and every pair: lo_tap_table_kernel forms them once per
+// call (the double arithmetic and the conversions are slow instructions; per row they cost more than the interpolation).
+// table[j], j < n (n = the row's float4 count * 4) = the tap of ROI column min(j, len - 1) as ONE float: the source
+// coordinate with the border rules already applied -- s0 + fx, which is exact: fx is what the coordinate's own
+// fraction bits hold -- so that the row pass recovers s0 = (int)t and fx = fract(t) in two instructions.
+__global__ void __launch_bounds__(256) lo_tap_table_kernel(float* table, int n, int len, int hi_x0, double scale, int sn)
+{
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    if (j >= n) return;
+    int s0; float fx;
+    lin_tap(hi_x0 + min(j, len - 1), scale, sn, s0, fx);
+    table[j] = (float)s0 + fx;
 }
 // floats per staged confidence row = shorts per staged disparity row: two of each fit the wave's M*256-byte buffer
 // (the shortest bucket's buffer is enlarged instead: its single float4 group per lane spans 256 columns)
@@ -145,6 +168,11 @@ __global__ void __launch_bounds__(64 * NW, (M > (NW == 2 ? 40 : ADF_H_TWO_WAVE_M
                 ss[hh] = __builtin_amdgcn_readfirstlane(s_first);
                 ns[hh] = __builtin_amdgcn_readfirstlane(s_last + 2 - s_first);      // 0 for an empty half
             }
+            // does a staged element of the half lie outside the confidence map's window (wave-uniform)?
+            bool need_mask[2];
+#pragma unroll
+            for (int hh = 0; hh < 2; hh++)
+                need_mask[hh] = a.lo_zero_outside && (!ADF_LO_NEEDMASK || yr[0] < a.lo_vy0 || yr[1] >= a.lo_vy1 || ss[hh] < a.lo_vx0 || min(ss[hh] + ns[hh], sw) > a.lo_vx1);
             // Per half: fetch the two source rows (coalesced: lane i takes source elements ss + 4i .. of the confidence
             // rows, ss + 8i .. of the disparity rows; a vector that would cross the row's end is fetched element by
             // element, clamped, which also fills the slots behind the row with the edge element), stage them, tap them.
@@ -182,75 +210,120 @@ __global__ void __launch_bounds__(64 * NW, (M > (NW == 2 ? 40 : ADF_H_TWO_WAVE_M
                     }
                 }
             };
-            float* Lf = reinterpret_cast<float*>(stage);
-            const short* Ls = reinterpret_cast<const short*>(stage) + 4 * CROW;      // behind the two confidence rows
+            // LDS layout: slot s of the half holds (row0[s], row1[s]) -- two floats of the confidence rows, then, behind
+            // all confidence slots, two shorts of the disparity rows -- so that a tap's four values (slots s and s + 1
+            // of both rows) are ONE 16-byte / ONE 8-byte read, and a lane, which holds the same source elements of
+            // both rows, stages them with whole 16-byte writes.
+            const float* Lf = reinterpret_cast<const float*>(stage);
+            const short* Ls = reinterpret_cast<const short*>(stage) + 4 * CROW;      // behind the 2 * CROW confidence floats
             v4f* Lf4 = reinterpret_cast<v4f*>(stage);
             typedef short s8a __attribute__((ext_vector_type(8)));
             s8a* Ls8 = reinterpret_cast<s8a*>(stage) + CROW / 2;
             auto put = [&](int hh, const v4f (&qc)[2][TC4], const s8u (&qd)[2][TD8]) {
+                const bool rin0 = !a.lo_zero_outside || (yr[0] >= a.lo_vy0 && yr[0] < a.lo_vy1);
+                const bool rin1 = !a.lo_zero_outside || (yr[1] >= a.lo_vy0 && yr[1] < a.lo_vy1);
 #pragma unroll
-                for (int r = 0; r < 2; r++) {
-                    const bool rin = !a.lo_zero_outside || (yr[r] >= a.lo_vy0 && yr[r] < a.lo_vy1);
+                for (int t = 0; t < TC4; t++) {
+                    const int i4 = 64 * t + lane, e = ss[hh] + 4 * i4;
+                    v4f q0 = qc[0][t], q1 = qc[1][t];
+                    if (need_mask[hh]) {
 #pragma unroll
-                    for (int t = 0; t < TC4; t++) {
-                        const int i4 = 64 * t + lane, e = ss[hh] + 4 * i4;
-                        v4f q = qc[r][t];
-                        if (a.lo_zero_outside) {
-#pragma unroll
-                            for (int c = 0; c < 4; c++) {
-                                const int ec = min(e + c, sw - 1);
-                                if (!(rin && ec >= a.lo_vx0 && ec < a.lo_vx1)) q[c] = 0.0f;
-                            }
+                        for (int c = 0; c < 4; c++) {
+                            const int ec = min(e + c, sw - 1);
+                            const bool cin = ec >= a.lo_vx0 && ec < a.lo_vx1;
+                            if (!(rin0 && cin)) q0[c] = 0.0f;
+                            if (!(rin1 && cin)) q1[c] = 0.0f;
                         }
-                        if (4 * i4 < CROW) Lf4[r * (CROW / 4) + i4] = q;
                     }
+                    if (4 * i4 < CROW) {
+                        Lf4[2 * i4] = v4f{q0[0], q1[0], q0[1], q1[1]};
+                        Lf4[2 * i4 + 1] = v4f{q0[2], q1[2], q0[3], q1[3]};
+                    }
+                }
 #pragma unroll
-                    for (int t = 0; t < TD8; t++) {
-                        const int i8 = 64 * t + lane;
-                        const s8u q = qd[r][t];
-                        if (8 * i8 < CROW) Ls8[r * (CROW / 8) + i8] = s8a{q[0], q[1], q[2], q[3], q[4], q[5], q[6], q[7]};
+                for (int t = 0; t < TD8; t++) {
+                    const int i8 = 64 * t + lane;
+                    const s8u q0 = qd[0][t], q1 = qd[1][t];
+                    if (8 * i8 < CROW) {
+                        Ls8[2 * i8] = s8a{q0[0], q1[0], q0[1], q1[1], q0[2], q1[2], q0[3], q1[3]};
+                        Ls8[2 * i8 + 1] = s8a{q0[4], q1[4], q0[5], q1[5], q0[6], q1[6], q0[7], q1[7]};
                     }
                 }
             };
+            typedef float f4a8 __attribute__((ext_vector_type(4), aligned(8)));
+            typedef short s4a4 __attribute__((ext_vector_type(4), aligned(4)));
+            typedef float v2f __attribute__((ext_vector_type(2)));
+            const v2f bb0 = {b0, b0}, bb1 = {b1, b1};
+            // the columns' taps (one float per column, the same for every row of the call: L2 hits)
+            v4f tp[MQ];
+            auto load_taps = [&](int hh) {
+#pragma unroll
+                for (int k = (hh ? KH : 0); k < (hh ? MQ : KH); k++) {
+                    const int idx = v0 + 64 * k + lane;
+                    tp[k] = v4f{0.f, 0.f, 0.f, 0.f};
+                    if (idx < nfused) tp[k] = reinterpret_cast<const v4f*>(a.lo_taps)[idx];
+                }
+            };
             fetch(0, rc[0], rd[0]);
+#if ADF_LO_TAPS_EARLY == 2
+            load_taps(0); load_taps(1);
+#endif
 #pragma unroll
             for (int hh = 0; hh < 2; hh++) {
+#if ADF_LO_TAPS_EARLY == 1
+                load_taps(hh);
+#endif
                 put(hh, rc[hh], rd[hh]);
                 __syncthreads();
                 if (hh == 0) {
                     asm volatile("" ::: "memory");               // (the next half's loads: not before this half is staged)
                     fetch(1, rc[1], rd[1]);
                 }
+#if ADF_LO_TAPS_EARLY == 0
+                load_taps(hh);
+#endif
 #pragma unroll
                 for (int k = (hh ? KH : 0); k < (hh ? MQ : KH); k++) {
-                    // (opaque: the taps depend on the lane index only, and the compiler would otherwise form all of them
-                    // -- eight registers per float4 -- while the loads are in flight, spilling the row)
+                    // (opaque: nothing here depends on a load, and the compiler would otherwise form every group's
+                    // taps while the loads are in flight, spilling the row)
                     int lane_t = lane;
                     asm volatile("" : "+v"(lane_t) :: "memory");
                     const int idx = v0 + 64 * k + lane_t;
+                    // all four columns' staged values first (eight LDS reads in flight), the arithmetic afterwards
+                    f4a8 cq[4]; s4a4 dq[4]; float fxs[4];
+#pragma unroll
+                    for (int c = 0; c < 4; c++) {
+                        const float t = tp[k][c];
+                        fxs[c] = __builtin_amdgcn_fractf(t);                          // exact: t = s0 + fx, t >= 0
+                        const int sl = min(max((int)t - ss[hh], 0), CROW - 2);          // (in range by construction; the clamp keeps a bug from reading other waves' LDS)
+                        cq[c] = *reinterpret_cast<const f4a8*>(Lf + 2 * sl);         // conf: row0[s], row1[s], row0[s+1], row1[s+1]
+                        dq[c] = *reinterpret_cast<const s4a4*>(Ls + 2 * sl);         // disparity, the same four
+                    }
                     float cv[4], dv[4];
 #pragma unroll
                     for (int c = 0; c < 4; c++) {
-                        const int col = 4 * idx + c;
-                        int s0; float fx;
-                        lin_tap(a.hi_x0 + min(col, a.len - 1), a.lo_scale_x, sw, s0, fx);
-                        const int sl = min(max(s0 - ss[hh], 0), CROW - 2);          // (in range by construction; the clamp keeps a bug from reading other waves' LDS)
-                        const float a0 = 1.0f - fx, a1 = fx;
-                        const float h0 = Lf[sl] * a0 + Lf[sl + 1] * a1;
-                        const float h1 = Lf[CROW + sl] * a0 + Lf[CROW + sl + 1] * a1;
-                        const float g0 = (float)Ls[sl] * a0 + (float)Ls[sl + 1] * a1;
-                        const float g1 = (float)Ls[CROW + sl] * a0 + (float)Ls[CROW + sl + 1] * a1;
-                        const float conf = h0 * b0 + h1 * b1;                       // DF.cpp:274
+                        // {confidence, disparity} side by side: packed multiplies / adds, every rounding where the scalar
+                        // statement has it (products and sums separately: no fused multiply-add)
+                        const float a0 = 1.0f - fxs[c], a1 = fxs[c];
+                        const v2f aa0 = {a0, a0}, aa1 = {a1, a1};
+                        const v2f p0 = {cq[c][0], (float)dq[c][0]}, p1 = {cq[c][1], (float)dq[c][1]};     // rows 0 / 1 at s
+                        const v2f n0 = {cq[c][2], (float)dq[c][2]}, n1 = {cq[c][3], (float)dq[c][3]};     // ... at s + 1
+                        const v2f h0 = p0 * aa0 + n0 * aa1, h1 = p1 * aa0 + n1 * aa1;
+                        const v2f v = h0 * bb0 + h1 * bb1;                          // DF.cpp:274 | DF.cpp:272
                         // saturate_cast<short> twice (DF.cpp:272, then x_ratio, :273) without branches: both arguments are
                         // finite and far inside the int range here (a convex combination of int16 values; that times the
                         // size ratio), so sat16's guard for NaN / out-of-int-range cannot fire -- and a branch per column
                         // would let the compiler sink every column's arithmetic behind the last one's (registers)
-                        const float q1 = fminf(fmaxf(rintf(g0 * b0 + g1 * b1), -32768.0f), 32767.0f);
+                        const float q1 = fminf(fmaxf(rintf(v[1]), -32768.0f), 32767.0f);
                         const float q2 = fminf(fmaxf(rintf(q1 * a.lo_post_scale), -32768.0f), 32767.0f);
-                        const float q = post_scaled ? q2 : q1;
-                        const bool on = col < a.len;
-                        cv[c] = on ? conf : 0.0f;
-                        dv[c] = on ? q : 0.0f;
+                        cv[c] = v[0];
+                        dv[c] = post_scaled ? q2 : q1;
+                    }
+                    // columns behind the row's end (the last, partial float4 and the lanes past it) are zero
+                    if (!ADF_LO_UMASK || 4 * (v0 + 64 * k + 64) > a.len) {       // (wave-uniform: only the group that holds the row's end, and those past it)
+                        const int left = a.len - 4 * idx;
+#pragma unroll
+                        for (int c = 0; c < 4; c++) { const bool on = c < left; cv[c] = on ? cv[c] : 0.0f; dv[c] = on ? dv[c] : 0.0f; }
                     }
                     t1[k] = make_float4(cv[0], cv[1], cv[2], cv[3]);               // U1 = conf, U0 = conf * float(dL)  (DF.cpp:288-290)
                     t0[k] = make_float4(cv[0] * dv[0], cv[1] * dv[1], cv[2] * dv[2], cv[3] * dv[3]);
@@ -438,7 +511,9 @@ hipError_t launch_h(const WavePassArgs& a, int n_rhs, int n_pairs, hipStream_t s
 {
     dim3 grid(a.nscan, n_pairs), block(64 * NW);
     if (a.lo_conf) {
-        if (n_rhs != 2) return hipErrorInvalidValue;
+        if (n_rhs != 2 || !a.lo_taps) return hipErrorInvalidValue;
+        const int n = ((a.len + 3) / 4) * 4;
+        hipLaunchKernelGGL(lo_tap_table_kernel, dim3((n + 255) / 256), dim3(256), 0, st, a.lo_taps, n, a.len, a.hi_x0, a.lo_scale_x, a.lo_w);
         hipLaunchKernelGGL((wave_hpass_kernel<M, 2, FUSE_LO, NW>), grid, block, 0, st, a);
     } else if (a.conf_in) {
         if (n_rhs != 2) return hipErrorInvalidValue;
@@ -482,7 +557,7 @@ bool wave_hpass_can_fuse(const WavePassArgs& a)
 // must keep rows 4-byte / 2-byte aligned.  The same tap function runs here and in the kernel.
 bool wave_hpass_can_fuse_lo(const WavePassArgs& a)
 {
-    if (!a.lo_conf || !a.lo_dl || a.lo_w < 2 || a.lo_h < 1 || a.len < 2 || a.len > wave_max_row_len()) return false;
+    if (!a.lo_conf || !a.lo_dl || a.lo_w < 2 || a.lo_w > 65535 || a.lo_h < 1 || a.len < 2 || a.len > wave_max_row_len()) return false;
     if ((reinterpret_cast<uintptr_t>(a.lo_conf) & 3u) != 0 || (reinterpret_cast<uintptr_t>(a.lo_dl) & 1u) != 0) return false;
     if (a.lo_dl_stride % 2 != 0 || a.lo_dl_pair % 2 != 0) return false;
     if (!(a.lo_scale_x > 0.0 && a.lo_scale_y > 0.0) || a.hi_x0 < 0 || a.hi_y0 < 0) return false;
