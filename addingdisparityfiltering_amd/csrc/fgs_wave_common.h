@@ -321,8 +321,11 @@ __device__ __forceinline__ void chunk_boundary2(const v2f (&c)[M], const v2f (&f
     o.GS0 = h0; o.GS1 = h1; o.PS = vqdiv<1>(a_s, dr, r); o.QS = q;
 }
 
-template <int M, int R>
-__device__ __forceinline__ void chunk_solve2(v2f (&c)[M], v2f (&f0)[M], v2f (&f1)[M], v2f a_s, v2f xL0, v2f xL1, v2f xR0, v2f xR1)
+// `emit(i, x0, x1)` is called the moment row i of the chunk is final -- the separator row first, then up the chunk as the
+// back-substitution forms them -- so that a caller can issue the row's store under the remaining arithmetic instead of
+// after it (round 4).
+template <int M, int R, typename Emit>
+__device__ __forceinline__ void chunk_solve2(v2f (&c)[M], v2f (&f0)[M], v2f (&f1)[M], v2f a_s, v2f xL0, v2f xL1, v2f xR0, v2f xR1, Emit&& emit)
 {
     constexpr bool NRS = ADF_WAVE_REFINE_SOLVE != 0;
     const v2f one = vsplat(1.0f), zero = vsplat(0.0f);
@@ -354,6 +357,7 @@ __device__ __forceinline__ void chunk_solve2(v2f (&c)[M], v2f (&f0)[M], v2f (&f1
     }
     v2f x0 = xR0, x1 = xR1;
     f0[M - 1] = x0; if (R > 1) f1[M - 1] = x1;
+    emit(M - 1, x0, x1);
 #pragma unroll
     for (int i = M - 2; i >= 0; i--) {
         x0 = vfma(-c[i], x0, f0[i]);
@@ -361,8 +365,14 @@ __device__ __forceinline__ void chunk_solve2(v2f (&c)[M], v2f (&f0)[M], v2f (&f1
         if (R > 1) { x1 = vfma(-c[i], x1, f1[i]); f1[i] = x1; }
         if (R > 1) asm volatile("" : "+v"(x0), "+v"(x1));
         else asm volatile("" : "+v"(x0));
+        emit(i, x0, x1);
         ADF_STEP_FENCE();
     }
+}
+template <int M, int R>
+__device__ __forceinline__ void chunk_solve2(v2f (&c)[M], v2f (&f0)[M], v2f (&f1)[M], v2f a_s, v2f xL0, v2f xL1, v2f xR0, v2f xR1)
+{
+    chunk_solve2<M, R>(c, f0, f1, a_s, xL0, xL1, xR0, xR1, [](int, v2f, v2f) {});
 }
 
 template <int M, int R>

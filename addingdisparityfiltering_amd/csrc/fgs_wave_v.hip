@@ -66,6 +66,9 @@ constexpr int VC = 16;   // columns per strip (the layouts' strip: fgs_wave_comm
 // (items issued after K) operations are outstanding -- anything else the compiler has in flight is older or younger
 // than all of them and only makes the wait stronger.
 // ---------------------------------------------------------------------------------------------
+#ifndef ADF_V_STORE_IN_SOLVE
+#define ADF_V_STORE_IN_SOLVE 0   // bit 0: plane passes, bit 1: the last pass -- a row's store is issued inside the back-substitution (round-4 experiment)
+#endif
 #ifndef ADF_V_GLDS
 #define ADF_V_GLDS 0   // 1: LDS-DMA whole-line loads (round-3 experiment, kept for A/B: the pass gains nothing, see below)
 #endif
@@ -164,7 +167,9 @@ __device__ __forceinline__ unsigned epi_pack16(v2f u0, v2f u1)
     return __builtin_bit_cast(unsigned, (s2)__builtin_amdgcn_cvt_pk_i16(i0, i1));
 }
 
-template <int M, int R, int EPI, int VCW = VC, int NCH = 64>
+// FS (round-4 experiment, ADF_V_STORE_IN_SOLVE): the rows are stored from inside the back-substitution; for the last pass
+// the launcher picks it when the packed 4-byte output stores apply (conditions uniform over the launch, checked on the host)
+template <int M, int R, int EPI, int VCW = VC, int NCH = 64, bool FS = false>
 __global__ void __launch_bounds__(VT) wave_vpass_kernel(WavePassArgs a)
 {
     static_assert((VCW == 16 && NCH == 64) || (VCW == 8 && NCH == 128), "whole strips of 64 chunks or half strips of 128");
@@ -338,6 +343,43 @@ __global__ void __launch_bounds__(VT) wave_vpass_kernel(WavePassArgs a)
             xL1 = (v2f){xs[1][cc][cidx - 1], xs[1][cc + 1][cidx - 1]};
         }
         ADF_STAMP(3);
+        // Round 4: a row is final the moment the back-substitution forms it; its store is issued
+        // there, under the remaining arithmetic, instead of in a loop of its own behind the solve.  The offsets walk
+        // UP the rows from the chunk's last one.
+        if constexpr (FS && EPI == EPI_PLANES) {
+            unsigned r0s = (unsigned)r0;
+            asm volatile("" : "+v"(r0s));        // (recomputed here: no load address stays alive across the sweeps)
+            const unsigned rl = r0s + (unsigned)(M - 1);
+            unsigned vo = (R > 1) ? ((rl / TR) * (2u * TR * (unsigned)a.pitch) + (unsigned)strip * (32u * TR) + (rl % TR) * 32u + c16) * 4u
+                                  : (rl * (unsigned)a.pitch + (unsigned)col) * 4u;
+            const int hv = h - (int)r0s;         // rows of this chunk inside the column
+            chunk_solve2<M, R>(c, f0, f1, a_s, xL0, xL1, xR0, xR1, [&](int i, v2f x0, v2f x1) {
+                if (i < hv) {
+                    *reinterpret_cast<v2f*>(b0 + vo) = x0;
+                    if (R > 1) *reinterpret_cast<v2f*>(b1 + vo) = x1;
+                }
+                if (i > 0) vo -= ADF_VSTEP(i - 1);
+            });
+            ADF_STAMP(4); ADF_STAMP(5); ADF_DRAIN(); ADF_STAMP(6); ADF_WSTAMP(1);
+            return;
+        } else if constexpr (FS) {
+            static_assert(!FS || EPI == EPI_PLANES || (R > 1 && EPI == EPI_WLS_CONF), "fused stores: plane passes and the disparity filter's last pass");
+            int r0e = r0, cole = col;
+            asm volatile("" : "+v"(r0e), "+v"(cole));
+            // (a wave-uniform base in scalar registers + one 32-bit offset per thread that walks up the rows)
+            char* obase = reinterpret_cast<char*>(a.out) + (ptrdiff_t)blockIdx.y * a.out_pair_stride + (ptrdiff_t)a.out_y0 * a.out_stride +
+                          (ptrdiff_t)a.out_x0 * 2;
+            const unsigned os = (unsigned)a.out_stride;
+            unsigned oo = (unsigned)(r0e + (M - 1)) * os + (unsigned)cole * 2u;
+            const int hv = (cole < a.nscan ? h : 0) - r0e;
+            chunk_solve2<M, R>(c, f0, f1, a_s, xL0, xL1, xR0, xR1, [&](int i, v2f x0, v2f x1) {
+                const unsigned v = epi_pack16<EPI>(x0, x1);
+                if (i < hv) *reinterpret_cast<unsigned*>(obase + oo) = v;
+                oo -= os;
+            });
+            ADF_STAMP(4); ADF_STAMP(5); ADF_DRAIN(); ADF_STAMP(6); ADF_WSTAMP(1);
+            return;
+        }
         chunk_solve2<M, R>(c, f0, f1, a_s, xL0, xL1, xR0, xR1);
         ADF_STAMP(4);
     }
@@ -445,16 +487,21 @@ hipError_t launch_v(const WavePassArgs& a, int n_rhs, int epi, int n_pairs, hipS
 {
     dim3 grid(a.pitch / VCW, n_pairs), block(VT);
     const size_t ring = (size_t)(VT / 64) * VRing<M>::SLOTS * 1024;
-#define ADF_LV(RR, EE)                                                                                        \
+#define ADF_LVF(RR, EE, FF)                                                                                   \
     do {                                                                                                      \
         const size_t lds = ((RR) > 1 && ADF_V_GLDS && VCW == VC) ? ring : 0;                                  \
         if (lds > 16 * 1024) {                                                                                \
-            hipError_t e = v_allow_lds(wave_vpass_kernel<M, RR, EE, VCW, NCH>, lds);                          \
+            hipError_t e = v_allow_lds(wave_vpass_kernel<M, RR, EE, VCW, NCH, FF>, lds);                      \
             if (e != hipSuccess) return e;                                                                    \
         }                                                                                                     \
-        hipLaunchKernelGGL((wave_vpass_kernel<M, RR, EE, VCW, NCH>), grid, block, lds, st, a);                \
+        hipLaunchKernelGGL((wave_vpass_kernel<M, RR, EE, VCW, NCH, FF>), grid, block, lds, st, a);            \
     } while (0)
-    if (n_rhs == 2 && epi == EPI_PLANES) ADF_LV(2, EPI_PLANES);
+#define ADF_LV(RR, EE) ADF_LVF(RR, EE, false)
+    // (the packed 4-byte stores of the last pass: single-channel output, even ROI width, everything 4-byte aligned)
+    const bool packed_out = a.out_cn == 1 && (a.nscan & 1) == 0 && ((a.out_x0 * 2) & 3) == 0 &&
+                            ((reinterpret_cast<uintptr_t>(a.out) | (uintptr_t)a.out_stride | (uintptr_t)a.out_pair_stride) & 3u) == 0;
+    if (n_rhs == 2 && epi == EPI_PLANES) ADF_LVF(2, EPI_PLANES, (ADF_V_STORE_IN_SOLVE & 1) != 0);
+    else if (n_rhs == 2 && epi == EPI_WLS_CONF && (ADF_V_STORE_IN_SOLVE & 2) && packed_out) ADF_LVF(2, EPI_WLS_CONF, (ADF_V_STORE_IN_SOLVE & 2) != 0);
     else if (n_rhs == 2 && epi == EPI_WLS_CONF) ADF_LV(2, EPI_WLS_CONF);
     else if (n_rhs == 1 && epi == EPI_PLANES) ADF_LV(1, EPI_PLANES);
     else if (n_rhs == 1 && epi == EPI_I16) ADF_LV(1, EPI_I16);
@@ -465,6 +512,7 @@ hipError_t launch_v(const WavePassArgs& a, int n_rhs, int epi, int n_pairs, hipS
     else if (n_rhs == 2 && epi == EPI_U8) ADF_LV(2, EPI_U8);
     else return hipErrorInvalidValue;
 #undef ADF_LV
+#undef ADF_LVF
     return hipGetLastError();
 }
 
