@@ -33,6 +33,9 @@ namespace prep {
 #ifndef ADF_WS_GROUP
 #define ADF_WS_GROUP 4
 #endif
+#ifndef ADF_WS_PAIR_ROWS
+#define ADF_WS_PAIR_ROWS 0   // 1: strip-major Cvert is stored two rows at a time, whole 128-byte lines per instruction (round-4 experiment: correct, no faster -- profiles/r04_ab_weights_pair_rows.txt)
+#endif
 constexpr int WS_U = ADF_WS_GROUP;             // rows in flight per lane (prefetch group)
 constexpr int WS_NT = 128;                     // threads of a block of the streaming weight kernel
 constexpr int WS_COLS = 4;                     // columns per lane
@@ -186,6 +189,11 @@ struct WsOut {
         vo = (strip ? ((unsigned)(j0 >> 4) * (unsigned)g.rh + (unsigned)y_first) * ADF_STRIP + (unsigned)(j0 & 15)
                     : (unsigned)y_first * (unsigned)g.pw + (unsigned)j0) * 4u;                     // ... of Cvert(y_first, j0)
         hstep = (unsigned)g.pw * 4u; vstep = (strip ? (unsigned)ADF_STRIP : (unsigned)g.pw) * 4u;
+#if ADF_WS_PAIR_ROWS
+        pair_back = (unsigned)g.rh * ADF_STRIP * 4u;
+#pragma unroll
+        for (int k = 0; k < WS_COLS; k++) held[k] = 0u;
+#endif
     }
     // Chor of ROI row y_first + t (`on`: uniform -- this step has such a row)
     __device__ __forceinline__ void store_h(int t, const float (&wh)[WS_COLS], bool on) const
@@ -216,6 +224,49 @@ struct WsOut {
         if (strip) __builtin_amdgcn_raw_buffer_store_b128(o, cvert, off, 0, 0);
         else __builtin_amdgcn_raw_buffer_store_b128(o, cvert, off, 0, 2);
     }
+#if ADF_WS_PAIR_ROWS
+    // Strip-major Cvert, two rows at a time (round 4): a strip row is 64 bytes, so a store of ONE row writes half lines
+    // -- sixteen 64-byte pieces per instruction.  With the weights of rows t-1 (held) and t (fresh) in hand, the two
+    // halves of every group of eight lanes -- two strips -- trade them (lane L and lane L ^ 4), and each of the two
+    // stores then writes whole 128-byte lines: strip s rows (t-1, t) from lanes (0..3 | 4..7), then strip s + 1.
+    // t - 1 must be even for the pair to start a line (the launcher makes the blocks' first rows even).
+    unsigned held[WS_COLS];
+    __device__ __forceinline__ void mask_v(const float (&wv)[WS_COLS], bool last_row, unsigned (&o)[WS_COLS]) const
+    {
+        const unsigned last = last_row ? 0u : 0xffffffffu;
+#pragma unroll
+        for (int k = 0; k < WS_COLS; k++) o[k] = __float_as_uint(wv[k]) & mv[k] & last;
+    }
+    // (`on`: uniform -- the step has such a row; steps past the block's last row must not disturb what is held)
+    __device__ __forceinline__ void hold_v(const float (&wv)[WS_COLS], bool last_row, bool on)
+    {
+        unsigned o[WS_COLS];
+        mask_v(wv, last_row, o);
+#pragma unroll
+        for (int k = 0; k < WS_COLS; k++) held[k] = on ? o[k] : held[k];
+    }
+    // rows t - 1 (held) and t (`wv`); `on`: uniform -- both rows exist
+    __device__ __forceinline__ void store_v_pair(int t, const float (&wv)[WS_COLS], bool last_row, bool on, int lane) const
+    {
+        unsigned b[WS_COLS];
+        mask_v(wv, last_row, b);
+        const bool hi = (lane & 4) != 0;                          // the lane's strip is the second of its group's two
+        ws_v4u s1, s2;
+#pragma unroll
+        for (int k = 0; k < WS_COLS; k++) {
+            const unsigned give = hi ? held[k] : b[k];            // what the partner stores for me
+            const unsigned got = (unsigned)__shfl_xor((int)give, 4);
+            s1[k] = hi ? got : held[k];                           // first strip:  rows t-1 (own, lanes 0..3) | t (from L-4)
+            s2[k] = hi ? b[k] : got;                              // second strip: rows t-1 (from L+4) | t (own, lanes 4..7)
+        }
+        // byte offset of (first strip of the pair, row t-1, this lane's piece) + one row for the upper four lanes
+        const unsigned base = vo + (unsigned)(t - 1) * vstep - (hi ? pair_back : 0u) + (hi ? vstep : 0u);
+        const bool ok = on && st_ok;
+        __builtin_amdgcn_raw_buffer_store_b128(s1, cvert, ok ? base : WS_DROP, 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b128(s2, cvert, ok ? base + pair_back : WS_DROP, 0, 0);
+    }
+    unsigned pair_back;                                           // bytes from a strip's stream to the next strip's: rh * 64
+#endif
 };
 
 // Block (bx, by) of nby row blocks, image pz.  `active`: the thread is one of the WS_NT that do the work -- a launch
@@ -233,6 +284,9 @@ __device__ __forceinline__ void weights_stream_body(const WeightArgs& a, int bx,
     __syncthreads();
     const int ws_rows = (g.rh + nby - 1) / nby;
     const int x0 = bx * WS_BCOLS, y0 = by * ws_rows;
+#if ADF_WS_PAIR_ROWS
+    const bool pair_rows = (ws_rows & 1) == 0 || nby == 1;       // every block starts on an even ROI row (uniform over the launch)
+#endif
     if (!active || y0 >= g.rh) return;
 #ifndef ADF_WS_PRIO
 #define ADF_WS_PRIO 3
@@ -293,10 +347,28 @@ __device__ __forceinline__ void weights_stream_body(const WeightArgs& a, int bx,
             float wh[WS_COLS], wv[WS_COLS];
             ws_lookup_finish(pend, wh, wv);
             out.store_h(n, wh, n < nrows - 1);                                         // Chor of ROI row y0+n, FGS.cpp:607-614
+#if ADF_WS_PAIR_ROWS
+            static_assert(WS_U % 2 == 0, "row pairs need an even prefetch group");
+            if (out.strip && pair_rows) {
+                // Cvert of the previous row (t = n - 1, FGS.cpp:635-660): even t is held, odd t goes out with it as whole lines
+                // (t's parity is known at compile time: n0 is a multiple of WS_U, the block's first row is even)
+                if (((s + WS_U - 1) & 1) == 0) out.hold_v(wv, y0 + n - 1 == g.rh - 1, n >= 1 && n < nrows);
+                else out.store_v_pair(n - 1, wv, y0 + n - 1 == g.rh - 1, n >= 2 && n < nrows, tid);
+            } else
+#endif
             out.store_v(n - 1, wv, y0 + n - 1 == g.rh - 1, n >= 1 && n < nrows);       // Cvert of the previous row, FGS.cpp:635-660
             pend = ahead;
         }
     }
+#if ADF_WS_PAIR_ROWS
+    // a block with an odd number of rows (only the ROI's last block, when rh is odd): its last row was held, never paired
+    if (out.strip && pair_rows && ((nrows - 1) & 1)) {
+        float wv[WS_COLS];
+#pragma unroll
+        for (int k = 0; k < WS_COLS; k++) wv[k] = __uint_as_float(out.held[k]);
+        out.store_v(nrows - 2, wv, false, true);                 // (already masked, the last row already zero)
+    }
+#endif
 }
 
 
