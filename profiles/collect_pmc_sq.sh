@@ -9,7 +9,14 @@ args="bench.py --pairs 8 --steps 1 --warmup 1 --cpu-seconds 0 --no-check --match
 i=0
 for grp in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_LDS" \
            "SQ_INST_CYCLES_VMEM_WR SQ_INST_CYCLES_VMEM_RD SQ_VMEM_WR_TA_DATA_FIFO_FULL SQ_VMEM_TA_ADDR_FIFO_FULL SQ_VMEM_TA_CMD_FIFO_FULL SQ_INST_LEVEL_VMEM SQ_WAVES SQ_ACTIVE_INST_SCA"; do
-  # (a third pass with TA_* counters aborted inside rocprofv3 on this image and hung the call: not collected)
+  # A third group of TA_* counters was tried in round 3 and is NOT collected.  Cause, from that pass's own log
+  # (gpurun_out/r03_sq_3.log, first lines): rocprofv3 refused the group before any kernel ran --
+  #   "rocprofiler_create_counter_config ... Could not construct profile cfg failed with error code 38: Request exceeds the
+  #    capabilities of the hardware to collect"
+  # -- i.e. the group asked for more TA counters than one pass has registers for; rocprofv3 then died on its own glog
+  # FATAL (signal 6) and the wrapped python was left waiting, which is what hung the call.  The tool, not a kernel of
+  # this library: the same command with the two groups below completes.  A TA_* set would have to go one counter per
+  # pass; the two SQ groups answer the question (who waits on what), so it is dropped rather than re-run.
   i=$((i+1))
   rm -rf gpurun_out/r03_sq_$i
   rocprofv3 --kernel-trace --pmc $grp -d gpurun_out/r03_sq_$i -o pmc --output-format csv -- python3 $args > gpurun_out/r03_sq_$i.log 2>&1
