@@ -643,7 +643,17 @@ def next_rows_leg(adf, torch, dev, synthetic, cfg, W, H, ch, seed, n, radius, ch
         n2["checked"] = {"exact_solver_bit_exact": bool(np.array_equal(got, exp)),
                          "wave_solver_max_abs_diff": float(np.abs(dst.cpu().numpy() - exp).max())}
     res["fgs_one_shot"] = n2
-    res["note"] = "SURVEY 8(f) rows N1 / N2 on the final kernels; not part of `value`"
+    # ---- BASELINE config 5 as the stream it is (tools/stream_cfg5.py): one 1242x375 frame per call on K handles / streams,
+    # sustained rate and per-frame latency, and the same frames as micro-batches
+    try:
+        import importlib.util
+        spec = importlib.util.spec_from_file_location("adf_stream_cfg5", os.path.join(ROOT, "tools", "stream_cfg5.py"))
+        mod = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(mod)
+        res["config5_stream"] = mod.measure(adf, torch, dev, synthetic, frames=256, check=check)
+    except Exception as e:
+        res["config5_stream"] = {"error": "%s: %s" % (type(e).__name__, e)}
+    res["note"] = "SURVEY 8(f) rows N1 / N2 on the final kernels, and config 5 one frame per call; not part of `value`"
     return res
 
 
