@@ -106,7 +106,7 @@ struct DevBuf {
         if (need <= bytes) return ADF_OK;
         if (p) { HIP_TRY(hipStreamSynchronize(st)); HIP_TRY(hipFree(p)); p = nullptr; bytes = 0; }
         need = (need + 255) / 256 * 256;
-        HIP_TRY(hipMalloc(&p, need));
+        HIP_TRY(adf::device_malloc(&p, need));
         bytes = need;
         // deterministic padding lanes: the sweeps read (and discard) pitch padding
         HIP_TRY(hipMemsetAsync(p, 0, need, st));
@@ -1207,21 +1207,31 @@ struct adf_fgs {
     // and where the previous call's result may still be copied out on another stream).  At destruction the block goes
     // to the cache together with this event.
     hipEvent_t busy = nullptr;
-    bool in_capture = false;      // a call was captured into a graph: the event is no ordinary event any more
+    bool in_capture = false;      // a call was captured into a graph at some point: replays may be in flight that `busy` does not cover
 };
 
+static bool stream_is_capturing(hipStream_t st)
+{
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(st, &cs) != hipSuccess) { (void)hipGetLastError(); return false; }
+    return cs != hipStreamCaptureStatusNone;
+}
+
+// A call that is being CAPTURED into a graph neither waits for nor records the handle's event (an event recorded
+// outside the capture has no place inside it, and one recorded inside is a graph node, not a marker on a stream);
+// every other call does both -- also after a capture: the state is not latched (round 4).  `in_capture` only remembers
+// that replays the library cannot see may exist, for adf_fgs_destroy.  include/adf_wls.h: a captured handle is used
+// on ONE stream.
 static int fgs_begin(adf_fgs* f, hipStream_t st)
 {
-    if (f->busy && !f->in_capture) HIP_TRY(hipStreamWaitEvent(st, f->busy, 0));
+    if (f->busy && !stream_is_capturing(st)) HIP_TRY(hipStreamWaitEvent(st, f->busy, 0));
     return ADF_OK;
 }
 
 static int fgs_end(adf_fgs* f, hipStream_t st)
 {
-    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
-    if (hipStreamIsCapturing(st, &cs) != hipSuccess) { (void)hipGetLastError(); cs = hipStreamCaptureStatusNone; }
-    if (cs != hipStreamCaptureStatusNone) { f->in_capture = true; return ADF_OK; }
-    if (f->busy && !f->in_capture) HIP_TRY(hipEventRecord(f->busy, st));
+    if (stream_is_capturing(st)) { f->in_capture = true; return ADF_OK; }
+    if (f->busy) HIP_TRY(hipEventRecord(f->busy, st));
     return ADF_OK;
 }
 
@@ -1256,11 +1266,7 @@ static int fgs_create_impl(adf_fgs_t** out, const uint8_t* guide, ptrdiff_t gstr
     hipError_t e = hipSuccess;
     f->block = BlockCache::get().take(f->device, planes_bytes + io_bytes, st, &f->block_bytes);
     if (!f->block) {
-        e = hipMalloc(&f->block, planes_bytes + io_bytes);
-        if (e != hipSuccess) {
-            BlockCache::get().clear();                               // the cache may be what fills the memory
-            e = hipMalloc(&f->block, planes_bytes + io_bytes);
-        }
+        e = adf::device_malloc(&f->block, planes_bytes + io_bytes);  // (clears the cache and retries when the driver refuses)
         if (e != hipSuccess) {
             f->block = nullptr; adf_fgs_destroy(f);
             return fail(e == hipErrorOutOfMemory ? ADF_ENOMEM : ADF_EHIP, "adf_fgs_create: %s", hipGetErrorString(e));
@@ -1315,6 +1321,20 @@ extern "C" int adf_weight_table_host(float sigma_color, float* table, int levels
     lut_build_host(sigma_color, table);
     return ADF_OK;
 }
+
+namespace adf {
+hipError_t device_malloc(void** p, size_t bytes)
+{
+    hipError_t e = hipMalloc(p, bytes);
+    if (e == hipErrorOutOfMemory) {
+        (void)hipGetLastError();
+        BlockCache::get().clear();                                   // the cache may be what fills the memory
+        e = hipMalloc(p, bytes);
+    }
+    if (e != hipSuccess) *p = nullptr;
+    return e;
+}
+} // namespace adf
 
 extern "C" void adf_release_cached_memory(void)
 {

@@ -182,6 +182,10 @@ struct WavePassArgs {
 
 // Records the calling thread's last error message (adf_last_error) and returns `code`.
 int set_error(int code, const char* msg);
+// hipMalloc that, when the driver refuses, first hands the library's own cache of destroyed filters' device blocks
+// (up to 3 GB, adf_api.hip: BlockCache) back to the driver and tries once more: no call may fail for want of memory
+// the library itself is sitting on.
+hipError_t device_malloc(void** p, size_t bytes);
 
 // Launchers (defined in the .hip files).  All are asynchronous on `st`.
 hipError_t launch_discontinuity(const DiscArgs& a, int n_pairs, hipStream_t st);

@@ -468,18 +468,14 @@ __global__ void __launch_bounds__(VT) wave_vpass_kernel(WavePassArgs a)
     ADF_STAMP(5); ADF_DRAIN(); ADF_STAMP(6); ADF_WSTAMP(1);
 }
 
-// Dynamic LDS of a two-right-hand-side instantiation: the wave rings of the LDS-DMA loads.  Beyond 48 KiB the function
-// needs its limit raised -- per function AND device, so the "already done" note is kept per device.
+// Dynamic LDS of a two-right-hand-side instantiation: the wave rings of the LDS-DMA loads (A/B build -DADF_V_GLDS=1 only).
+// Beyond 48 KiB the function needs its limit raised, per function AND device.  No "already done" memo: one keyed on the
+// function's TYPE -- identical for every instantiation -- would skip the attribute for all kernels but the first
+// (ADVICE r3); the call is cheap next to a pass and only this experimental build makes it.
 template <typename K>
 hipError_t v_allow_lds(K kernel, size_t bytes)
 {
-    static unsigned long long done = 0;                       // bit d: raised on device d (devices >= 64: every launch)
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess) return hipErrorInvalidDevice;
-    if (dev < 64 && (__atomic_load_n(&done, __ATOMIC_RELAXED) >> dev & 1ull)) return hipSuccess;
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
-    if (e == hipSuccess && dev < 64) __atomic_fetch_or(&done, 1ull << dev, __ATOMIC_RELAXED);
-    return e;
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
 }
 
 template <int M, int VCW = VC, int NCH = 64>

@@ -476,7 +476,7 @@ int sg_reserve(void** p, size_t* have, size_t need, hipStream_t st)
     if (need <= *have) return ADF_OK;
     if (*p) { if (hipStreamSynchronize(st) != hipSuccess) return sg_fail(ADF_EHIP, "hipStreamSynchronize failed"); hipFree(*p); *p = nullptr; *have = 0; }
     need = (need + 255) / 256 * 256;
-    hipError_t e = hipMalloc(p, need);
+    hipError_t e = adf::device_malloc(p, need);   // (gives the filter cache's blocks back first if it must)
     if (e != hipSuccess) { *p = nullptr; return sg_fail(e == hipErrorOutOfMemory ? ADF_ENOMEM : ADF_EHIP, "hipMalloc failed for the matcher workspace"); }
     *have = need;
     return ADF_OK;

@@ -227,7 +227,9 @@ void adf_fgs_destroy(adf_fgs_t* h);
  * device) and 3*256*256 libm calls for the weight table on every call.  The library therefore keeps a destroyed
  * filter's device block (at most 8 blocks / 3 GB per process, handed to the next filter behind the event of its last
  * user: no host synchronisation) and the weight tables by (device, sigma) (16 of them).  This returns all of it to the
- * driver; it waits for the blocks' last users. */
+ * driver; it waits for the blocks' last users.  (The library does the same on its own whenever one of its device
+ * allocations -- a filter's workspace, a matcher's -- is refused for want of memory, and tries again; allocations the
+ * CALLER makes in the same process do not see the cache: call this before a large one.) */
 void adf_release_cached_memory(void);
 /* The weight table of a sigma_color exactly as the filters build it (FGS.cpp:150-154, 663-675: 3*256*256 entries
  * -exp(-sqrt(i)/sigma) through the host's libm; built by several threads, the underflowed tail stored as -0.0f without
@@ -243,7 +245,11 @@ int adf_fgs_filter_host(adf_fgs_t* h, const void* src, ptrdiff_t src_stride, voi
                         ptrdiff_t dst_stride, int depth, int channels);
 /* The same with DEVICE pointers, asynchronous on `stream` (a hipStream_t; NULL = the null
  * stream): for callers whose images already live in HBM (EdgeAwareInterpolator-style flow
- * post-filtering, sparse_match_interpolators.cpp:202-203).  dst may alias src. */
+ * post-filtering, sparse_match_interpolators.cpp:202-203).  dst may alias src.
+ * Stream capture: the call may be captured into a hipGraph.  Calls on different streams are ordered by an event the
+ * handle keeps; a call that is being captured neither waits for nor records it, so a handle whose calls are captured
+ * must be used on ONE stream (captured and ordinary calls alike), and destroyed outside any capture once its graphs'
+ * replays have finished (adf_fgs_destroy then synchronises the device instead of caching the handle's block). */
 int adf_fgs_filter_device(adf_fgs_t* h, const void* src, ptrdiff_t src_stride, void* dst,
                           ptrdiff_t dst_stride, int depth, int channels, void* stream);
 
