@@ -409,8 +409,27 @@ __global__ void __launch_bounds__(VT) wave_vpass_kernel(WavePassArgs a)
         // StereoBM factory's ROIs do: DF.cpp:401), as its two halves -- with no per-row alignment test and no branch but
         // the row mask.  Round 3: the general loop below spent 4.5 us per strip (of 38) on IEEE divisions, conversions
         // and exec-mask branches (profiles/r03_vphase.txt).  All three conditions are uniform over the launch.
-        const bool fast16 = (EPI == EPI_WLS_CONF || EPI == EPI_I16) && a.out_cn == 1 && (a.nscan & 1) == 0;
-        if (fast16) {
+        // Round 4: an ODD number of columns takes the same path -- the one thread per strip row that holds the ROI's last
+        // column stores its low half only (2 bytes), everything else is unchanged.
+        const bool fast16 = (EPI == EPI_WLS_CONF || EPI == EPI_I16) && a.out_cn == 1;
+        if (fast16 && (a.nscan & 1)) {
+            const bool al4 = ((reinterpret_cast<uintptr_t>(a.out) | (uintptr_t)a.out_stride | (uintptr_t)a.out_pair_stride) & 3u) == 0 &&
+                             ((a.out_x0 * 2) & 3) == 0;
+            const int hv2 = (cole + 1 < a.nscan ? h : 0) - r0e;   // rows of a thread with two columns inside the ROI
+            const int hv1 = (cole + 1 == a.nscan ? h : 0) - r0e;  // ... with only its first column inside
+            char* dst = ob + ooff;
+#pragma unroll
+            for (int i = 0; i < M; i++) {
+                const unsigned v = epi_pack16<EPI>(f0[i], f1[i]);
+                if (i < hv2) {
+                    if (al4) *reinterpret_cast<unsigned*>(dst) = v;
+                    else { reinterpret_cast<uint16_t*>(dst)[0] = (uint16_t)v; reinterpret_cast<uint16_t*>(dst)[1] = (uint16_t)(v >> 16); }
+                }
+                if (i < hv1) reinterpret_cast<uint16_t*>(dst)[0] = (uint16_t)v;
+                dst += a.out_stride;
+                ADF_STEP_FENCE();
+            }
+        } else if (fast16) {
             const bool al4 = ((reinterpret_cast<uintptr_t>(a.out) | (uintptr_t)a.out_stride | (uintptr_t)a.out_pair_stride) & 3u) == 0 &&
                              ((a.out_x0 * 2) & 3) == 0;
             const int hv = (cole < a.nscan ? h : 0) - r0e;        // rows of this thread to store (threads on pitch padding: none)

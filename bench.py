@@ -816,9 +816,9 @@ def build_line(args, dry, world, backend, n_total, pairs, W, H, ch, roi, roi_kin
         else:
             hname = "wave_hpass_kernel<%d, 2, false, 1>" % bucket((roi[2] + 63) // 64, (4, 8, 16, 20, 28, 40, 56, 60, 64))
         if roi[3] > 2176:
-            vname = "wave_vpass_kernel<%d, 2, 0, 8, 128>" % bucket((roi[3] + 127) // 128, (20, 26, 34))
+            vname = "wave_vpass_kernel<%d, 2, 0, 8, 128, false>" % bucket((roi[3] + 127) // 128, (20, 26, 34))
         else:
-            vname = "wave_vpass_kernel<%d, 2, 0, 16, 64>" % bucket((roi[3] + 63) // 64, (2, 4, 8, 12, 18, 26, 34))
+            vname = "wave_vpass_kernel<%d, 2, 0, 16, 64, false>" % bucket((roi[3] + 63) // 64, (2, 4, 8, 12, 18, 26, 34))
         names = {"pass_h": hname, "pass_v": vname}
     else:
         names = {"pass_h": "exact_pass_kernel<2, 0>", "pass_v": "exact_pass_kernel<2, 0>"}

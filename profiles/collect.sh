@@ -4,7 +4,7 @@
 # Outputs land in gpurun_out/ (scratch); profiles/summarize.py turns them into the committed summaries.
 set -e
 solver=${1:-wave}
-round=${ADF_ROUND:-r03}
+round=${ADF_ROUND:-r04}
 tag=gpurun_out/${round}_${solver}
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 rm -rf ${tag}_stats ${tag}_pmc_fetch ${tag}_pmc_write

@@ -21,7 +21,7 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 PAIRS = 8
-ROUND = os.environ.get("ADF_ROUND", "r03")
+ROUND = os.environ.get("ADF_ROUND", "r04")
 
 
 def kernel_sources_sha16():
