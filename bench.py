@@ -529,6 +529,9 @@ def worker(args):
                                args.cpu_seconds)
             line["cpu_baseline"] = cpu
             line["speedup_vs_cpu"] = round(line["value"] / cpu["value"], 1)
+            # which CPU figure the ratio divides by: the BEST of the thread sweep (cpu_baseline.cores threads, order in
+            # cpu_baseline.order) -- not the rate at getNumThreads() = all logical CPUs, which the sweep in `sample` also lists
+            line["speedup_vs_cpu_basis"] = "value / cpu_baseline.value = best of the thread sweep: %s order on %d threads" % (cpu.get("order"), cpu.get("cores"))
         except Exception as e:
             line["cpu_baseline"] = None
             line["cpu_baseline_error"] = str(e)
@@ -812,9 +815,9 @@ def build_line(args, dry, world, backend, n_total, pairs, W, H, ch, roi, roi_kin
     if args.solver == "wave":
         # (rows beyond 4096 columns: two wavefronts per row; columns beyond 2176 rows: half strips of 128 chunks)
         if roi[2] > 4096:
-            hname = "wave_hpass_kernel<%d, 2, false, 2>" % bucket((roi[2] + 127) // 128, (40, 48, 56, 60, 64))
+            hname = "wave_hpass_kernel<%d, 2, 0, 2>" % bucket((roi[2] + 127) // 128, (40, 48, 56, 60, 64))
         else:
-            hname = "wave_hpass_kernel<%d, 2, false, 1>" % bucket((roi[2] + 63) // 64, (4, 8, 16, 20, 28, 40, 56, 60, 64))
+            hname = "wave_hpass_kernel<%d, 2, 0, 1>" % bucket((roi[2] + 63) // 64, (4, 8, 16, 20, 28, 40, 56, 60, 64))
         if roi[3] > 2176:
             vname = "wave_vpass_kernel<%d, 2, 0, 8, 128, false>" % bucket((roi[3] + 127) // 128, (20, 26, 34))
         else:
