@@ -24,7 +24,7 @@
 // tracked a pair of disparities at a time: the winner pair and the pairs before / after it are captured as whole
 // registers (for the uniqueness test also the smallest pair minimum two or more pairs away), and which half won
 // is decided once at the end.  Nothing but the int16 result is written.
-// The kernel is bound by integer VALU issue (about 11 instructions per pixel and disparity), not
+// The kernel is bound by integer VALU issue (about 11 instructions per pixel and disparity; EXPERIMENTS.md section 10), not
 // by HBM: the views are read through L1/L2 once per disparity, HBM sees them once.
 #include "adf_internal.h"
 #include "../../include/adf_wls.h"

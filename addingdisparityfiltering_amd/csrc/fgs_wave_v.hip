@@ -52,7 +52,7 @@ constexpr int VC = 16;   // columns per strip (the layouts' strip: fgs_wave_comm
 // (tools/micro/vpattern.hip) this shape is 15 % faster than the register loads below, but in the pass every wave meets
 // the others at the barrier before the reduced system, so the strip is not done before its slowest wave's loads are:
 // A/B on the 64 x 4K step 4.25-4.29 ms (DMA) against 4.19-4.21 ms (register loads) for the two plain passes, and
-// the short columns of 1242 x 375 frames lose 8 % to the ring's LDS (profiles/r03_ab_glds.txt).
+// the short columns of 1242 x 375 frames lose 8 % to the ring's LDS (profiles/r03_ab_glds.txt, EXPERIMENTS.md section 9).
 // A thread owns (chunk, column pair), so loading straight into its registers
 // makes every wave instruction fetch 8 rows x 64 bytes at 8 bytes per lane ("fragment-shaped"): measured on the pass's
 // own layout (tools/micro/vpattern.hip, profiles/r03_vpattern.txt) that moves the pass's bytes at 4.5 TB/s, while

@@ -183,7 +183,7 @@ def cpu_baseline(view, dl, dr, roi, radius, seconds):
 
 def views_to_filtered(xi, view, n, num_disp, block, matcher="bm", check=True):
     """Extra leg, outside the timed region and not part of `value`: a device matcher (both views) feeding the
-    filter, all stages on torch's stream, inputs resident.
+    filter, all stages on torch's stream, inputs resident (EXPERIMENTS.md section 10).
 
     check: pair 0 against the oracle's pipeline -- the matcher's maps on the top rows of the frame (a block / 3-way
     semi-global match of row y reads no row below y + blockSize/2 + 2, so the oracle runs on a crop and finishes in
