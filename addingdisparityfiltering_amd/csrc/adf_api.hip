@@ -968,6 +968,7 @@ static int run_scaled_stage(const ScaledStage& s, hipStream_t st, Profiler* prof
         if (band_map) {
             // the one-sweep kernel at the maps' resolution: ROI pixels from the band kernel, zeros outside (DF.cpp:187-190)
             ConfBandArgs ba{s.dispL, s.sL, s.psL, s.dispR, s.sR, s.psR, s.clo, glo, rrx, thresh_lo, h->disc_radius, da.roll_off, 0};
+            h->last_path |= ADF_PATH_CONF_BAND;
             {
                 ProfScope ps(prof, K_LRC, 8.0 * Plo, 8.0 * Plo, st);
                 HIP_TRY(launch_conf_band(ba, n_pairs, st));                // DF.cpp:197-210

@@ -181,7 +181,7 @@ def cpu_baseline(view, dl, dr, roi, radius, seconds):
     }
 
 
-def views_to_filtered(xi, view, n, num_disp, block, matcher="bm", check=True):
+def views_to_filtered(xi, view, n, num_disp, block, matcher="bm", check=True, half=False):
     """Extra leg, outside the timed region and not part of `value`: a device matcher (both views) feeding the
     filter, all stages on torch's stream, inputs resident (EXPERIMENTS.md section 10).
 
@@ -190,6 +190,13 @@ def views_to_filtered(xi, view, n, num_disp, block, matcher="bm", check=True):
     seconds), then the filter of the device maps against the oracle's filter of the same maps on the whole frame."""
     import torch
     left = view[:n, :, :, 0].contiguous() if view.dim() == 4 else view[:n].contiguous()
+    if half:
+        # the sample's DEFAULT pipeline (samples/disparity_filtering.cpp:130-141,151-189): the matcher runs on HALF-size
+        # views with half the disparity range (window 7), the filter on the full view.  (The 8U resize / gray conversion
+        # of the views is OpenCV's and upstream of the path: the half-size views are made here, outside the timing.)
+        lf = left.to(torch.float32)
+        left = ((lf[:, 0::2, 0::2] + lf[:, 0::2, 1::2] + lf[:, 1::2, 0::2] + lf[:, 1::2, 1::2] + 2.0) * 0.25).floor().to(torch.uint8).contiguous()
+        num_disp = max(16, (num_disp // 2 + 15) // 16 * 16)
     right = torch.roll(left, -min(num_disp // 3, 60), 2).contiguous()
     if matcher == "sgbm":
         lm = xi.StereoSGBM.create(0, num_disp, block)
@@ -201,7 +208,9 @@ def views_to_filtered(xi, view, n, num_disp, block, matcher="bm", check=True):
     rm = xi.createRightMatcher(lm)                           # DF.cpp:417-449
     wls.setLambda(8000.0); wls.setSigmaColor(1.5)
     H, W = left.shape[1:]
-    dl = torch.empty((n, H, W), dtype=torch.int16, device=left.device); dr = torch.empty_like(dl); out = torch.empty_like(dl)
+    VH, VW = view.shape[1:3]
+    dl = torch.empty((n, H, W), dtype=torch.int16, device=left.device); dr = torch.empty_like(dl)
+    out = torch.empty((n, VH, VW), dtype=torch.int16, device=left.device)
     ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
     for it in range(2):                                      # first round warms the workspaces up
         ev[0].record()
@@ -217,10 +226,12 @@ def views_to_filtered(xi, view, n, num_disp, block, matcher="bm", check=True):
     fl = wls.getLastPath()
     res = {"matcher": matcher, "pairs": n, "num_disparities": num_disp, "block_size": block, "roi": list(wls.getROI()),
            "radius": wls.getDepthDiscontinuityRadius(),
-           "path": {"conf_band_kernel": bool(fl & xi.PATH_CONF_BAND), "fused_first_row_pass": bool(fl & xi.PATH_FUSED_FIRST_PASS)},
+           "path": {"conf_band_kernel": bool(fl & xi.PATH_CONF_BAND), "fused_first_row_pass": bool(fl & xi.PATH_FUSED_FIRST_PASS),
+                    "first_pass_interpolates_low_resolution_maps": bool(fl & xi.PATH_SCALED_FUSED)},
+           "maps": "%dx%d" % (W, H), "view": "%dx%d" % (VW, VH),
            "matcher_ms_per_pair": round(ev[0].elapsed_time(ev[1]) / n, 4),
            "filter_ms_per_pair": round(ev[1].elapsed_time(ev[2]) / n, 4),
-           "Mpixels_per_s": round(n * H * W / (ev[0].elapsed_time(ev[2]) * 1e-3) / 1e6, 1),
+           "Mpixels_per_s": round(n * VH * VW / (ev[0].elapsed_time(ev[2]) * 1e-3) / 1e6, 1),
            "note": "left + right view matcher then the filter, each one call for the batch; not part of `value`"}
     if check:
         import numpy as np
@@ -238,13 +249,17 @@ def views_to_filtered(xi, view, n, num_disp, block, matcher="bm", check=True):
         p = oracle.default_params(sigma_color=1.5, disc_radius=wls.getDepthDiscontinuityRadius(),
                                   threads=len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else 8)
         p.lambda_ = 8000.0
-        exp, exp_conf = oracle.wls_filter(gl, view[0].cpu().numpy(), gr, wls.getROI(), p)
+        if half:
+            exp, exp_conf = oracle.wls_filter_scaled(gl, view[0].cpu().numpy(), gr, wls.getROI(), p)
+        else:
+            exp, exp_conf = oracle.wls_filter(gl, view[0].cpu().numpy(), gr, wls.getROI(), p)
         diff = np.abs(out[0].cpu().numpy().astype(np.int64) - exp)
         conf_ok = bool(np.array_equal(wls.getConfidenceMap(0).cpu().numpy(), exp_conf))
         res["checked"] = bool(maps_ok and conf_ok and diff.max() <= 1 and diff.mean() <= 1 / 256)
         res["check"] = {"pair": 0, "matcher_maps_bit_exact_rows": [0, rows] if maps_ok else False, "confidence_bit_exact": conf_ok,
                         "disparity_max_abs_lsb": int(diff.max()), "disparity_mean_abs_lsb": float(diff.mean()),
                         "valid_fraction_left_map": float((gl[:, num_disp:] >= 0).mean())}
+        # (half: the filter's ROI is in the maps' coordinates, DF.cpp:229-230; the oracle's scaled call takes it the same way)
     else:
         res["checked"] = None
     return res
@@ -541,9 +556,10 @@ def worker(args):
     if rank == 0 and world == 1 and args.matcher_pairs > 0 and not dry:
         nd = max(16, (cfg["roi"][0] + 15) // 16 * 16)       # the config's ROI x is its numDisparities
         pipeline = {}
-        for m, blk in (("bm", 15), ("sgbm", 3)):
+        for m, blk in (("bm", 15), ("sgbm", 3), ("bm_half", 7)):
             try:
-                pipeline[m] = views_to_filtered(adf, view, min(args.matcher_pairs, pairs), min(nd, 256), blk, m, not args.no_check)
+                pipeline[m] = views_to_filtered(adf, view, min(args.matcher_pairs, pairs), min(nd, 256), blk, m.split("_")[0],
+                                                not args.no_check, half=m.endswith("_half"))
             except Exception as e:                           # the extra leg must never cost the bench line
                 pipeline[m] = {"error": str(e)}
         line["views_to_filtered"] = pipeline
