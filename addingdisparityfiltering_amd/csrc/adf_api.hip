@@ -98,6 +98,13 @@ struct DeviceScope {
     ~DeviceScope() { if (switched) hipSetDevice(prev); }
 };
 
+static bool stream_is_capturing(hipStream_t st)
+{
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(st, &cs) != hipSuccess) { (void)hipGetLastError(); return false; }
+    return cs != hipStreamCaptureStatusNone;
+}
+
 // Growable device buffer (never shrinks; freed with the handle).
 struct DevBuf {
     void* p = nullptr; size_t bytes = 0;
@@ -620,6 +627,7 @@ static int run_scaled_stage(const ScaledStage& s, hipStream_t st, Profiler* prof
 // stage asked for it; false = the resize kernels run
 static bool scaled_fuse_lo(const ScaledStage& s, int first, const Geom& g, WavePassArgs& fuse);
 static void scaled_note_lazy_conf(const ScaledStage& s);
+static int scaled_resize_conf_now(const ScaledStage& s, hipStream_t st, Profiler* prof);
 
 // conf_given: the down-scaled path (DF.cpp:274): the confidence kernels are skipped and dispR is not used; `scaled`
 // (may be null) fills h->conf with the view-sized confidence planes of all pairs and produces dispL itself.
@@ -785,7 +793,13 @@ static int wls_filter_impl(adf_wls_t* h, int n_pairs,
                 if (lo_fused) {
                     // the first row pass taps the low-resolution maps itself: no resize launch, no view-sized planes
                     h->last_path |= ADF_PATH_SCALED_FUSED;
-                    if (first == 0) scaled_note_lazy_conf(*scaled);
+                    if (first == 0) {
+                        if (stream_is_capturing(st)) {
+                            // a call captured into a graph is replayed without this host code: the view-sized confidence
+                            // maps are made inside the call (the graph), so getConfidenceMap() stays current after replays
+                            if ((rc = scaled_resize_conf_now(*scaled, st, prof))) return rc;
+                        } else scaled_note_lazy_conf(*scaled);
+                    }
                 } else {
                 fuse.conf_in = confp; fuse.conf_frame = g.cframe; fuse.conf_pitch = g.cpitch; fuse.conf_x0 = g.cx0 + roi.x; fuse.conf_y0 = roi.y;
                 fuse.dl_in = dL; fuse.dl_stride = sL; fuse.dl_pair_stride = psL; fuse.dl_x0 = roi.x; fuse.dl_y0 = roi.y;
@@ -940,6 +954,11 @@ static int resize_conf_planes(adf_wls_t* h, const float* clo, int dW, int dH, co
     ProfScope ps(prof, K_RESIZE, 4.0 * Fhi + 4.0 * (double)lo * n_pairs, 4.0 * Fhi + 4.0 * (double)lo * n_pairs, st);
     HIP_TRY(launch_resize_linear(rc32, n_pairs, st));
     return ADF_OK;
+}
+
+static int scaled_resize_conf_now(const ScaledStage& s, hipStream_t st, Profiler* prof)
+{
+    return resize_conf_planes(s.h, s.clo, s.dW, s.dH, s.rlo, s.ghi, scaled_band_map(s), s.n_pairs, st, prof);
 }
 
 // part 0: the low-resolution confidence map; part 1: the two resizes.  Both are queued beside the weight kernel (after
@@ -1210,13 +1229,6 @@ struct adf_fgs {
     hipEvent_t busy = nullptr;
     bool in_capture = false;      // a call was captured into a graph at some point: replays may be in flight that `busy` does not cover
 };
-
-static bool stream_is_capturing(hipStream_t st)
-{
-    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
-    if (hipStreamIsCapturing(st, &cs) != hipSuccess) { (void)hipGetLastError(); return false; }
-    return cs != hipStreamCaptureStatusNone;
-}
 
 // A call that is being CAPTURED into a graph neither waits for nor records the handle's event (an event recorded
 // outside the capture has no place inside it, and one recorded inside is a graph node, not a marker on a stream);

@@ -255,3 +255,36 @@ def test_fused_scaled_batch_chunks_and_lazy_confidence(adf, oracle):
     e1, c1 = oracle.wls_filter(l1, v1, r1, roi1, oracle.default_params(sigma_color=1.5, threads=8))
     assert np.array_equal(f1.getConfidenceMap(), c1)
     assert np.abs(out1.astype(np.int64) - e1).max() <= 1
+
+
+@pytest.mark.gpu
+def test_fused_scaled_call_captured_into_a_graph(adf, oracle):
+    """A down-scaled call captured into a hipGraph is replayed without the library's host code, so the confidence maps
+    cannot be left for later: inside a capture they are made by the call itself and stay current after every replay."""
+    import torch
+
+    dev = torch.device("cuda:0")
+    w, h = 512, 256
+    va, la, ra, roi = _scaled_inputs(w, h, w // 2, h // 2, 3, seed=31)
+    vb, lb, rb, _ = _scaled_inputs(w, h, w // 2, h // 2, 3, seed=47)
+    tv, tl, tr = (torch.from_numpy(a).to(dev) for a in (va, la, ra))
+    out = torch.empty((h, w), dtype=torch.int16, device=dev)
+    f = adf.createDisparityWLSFilterGeneric(True)
+    f.setSolver(adf.SOLVER_WAVE); f.setSigmaColor(1.5)
+    f.filter(tl, tv, out, tr, roi)                                   # workspace and weight table exist before the capture
+    torch.cuda.synchronize()
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g, stream=s):
+        f.filter(tl, tv, out, tr, roi)
+    assert f.getLastPath() & adf.PATH_SCALED_FUSED
+    p = oracle.default_params(sigma_color=1.5, threads=8)
+    for view, dl, dr in ((va, la, ra), (vb, lb, rb), (va, la, ra)):
+        tv.copy_(torch.from_numpy(view)); tl.copy_(torch.from_numpy(dl)); tr.copy_(torch.from_numpy(dr))
+        g.replay()
+        torch.cuda.synchronize()
+        exp, exp_conf = oracle.wls_filter_scaled(dl, view, dr, roi, p)
+        assert np.array_equal(f.getConfidenceMap().cpu().numpy(), exp_conf)
+        d = np.abs(out.cpu().numpy().astype(np.int64) - exp)
+        assert d.max() <= 1 and d.mean() <= 1 / 256
