@@ -33,6 +33,7 @@ Everything else is a measured distance, gated in tests/test_tutorial_replay.py b
 
     python tests/tutorial_replay.py            the oracle leg, prints the table (CPU)
     python tests/tutorial_replay.py --hip      the HIP leg next to it (GPU box)
+    python tests/tutorial_replay.py --speckles the raw-map comparison again with our map's speckles removed (slow, analysis)
 """
 import math
 import os
@@ -119,6 +120,34 @@ def raw_bm_oracle(left, right):
     return oracle.disparity_vis(d, VIS_MULT), rect
 
 
+def remove_speckles(disp, new_val, max_size, max_diff):
+    """cv::filterSpeckles restated for the report below (analysis only -- the filter's pipeline forces the matchers'
+    speckle filter off, DF.cpp:390,429,441, and the product has none): 4-connected components whose neighbouring
+    disparities differ by at most max_diff; components of at most max_size pixels become new_val."""
+    from collections import deque
+
+    H, W = disp.shape
+    seen = np.zeros((H, W), bool)
+    out = disp.copy()
+    for y in range(H):
+        for x in range(W):
+            if seen[y, x] or disp[y, x] == new_val:
+                continue
+            seen[y, x] = True
+            q, comp = deque([(y, x)]), [(y, x)]
+            while q:
+                cy, cx = q.popleft()
+                v = int(disp[cy, cx])
+                for ny, nx in ((cy - 1, cx), (cy + 1, cx), (cy, cx - 1), (cy, cx + 1)):
+                    if 0 <= ny < H and 0 <= nx < W and not seen[ny, nx] and disp[ny, nx] != new_val and abs(int(disp[ny, nx]) - v) <= max_diff:
+                        seen[ny, nx] = True
+                        q.append((ny, nx)); comp.append((ny, nx))
+            if len(comp) <= max_size:
+                for yy, xx in comp:
+                    out[yy, xx] = new_val
+    return out
+
+
 def replay_hip(left, right, solver=None):
     """The same pipeline through the product's Python mirror of the reference API, everything past the 8U host
     preparation on the device."""
@@ -181,6 +210,15 @@ def main(argv):
     print(fmt("oracle filtered vs ambush_5_bm_with_filter.png (ROI)", distance(o["vis"], pub_filtered, o["roi"])))
     rv, rect = raw_bm_oracle(left, right)
     print(fmt("oracle StereoBM(128,9) vs ambush_5_bm.png (valid in both)", distance(rv, pub_bm, rect, True)))
+    if "--speckles" in argv:
+        # The published raw map has no isolated blobs: it looks speckle-filtered (parameters unknown).  With the outliers
+        # of OUR map removed the same way, what remains agrees with calib3d's map almost everywhere it is valid in both.
+        import oracle
+
+        d = oracle.bm_compute(bgr2gray(left), bgr2gray(right), RAW_NUM_DISP, RAW_WSIZE, 0, 31, RAW_TEXTURE, RAW_UNIQUENESS)
+        for size, diff in ((100, 32), (400, 32)):
+            v = oracle.disparity_vis(remove_speckles(d, -16, size, diff), VIS_MULT)
+            print(fmt("  ... speckles <= %d px (range %d/16 px) removed from ours" % (size, diff), distance(v, pub_bm, rect, True)))
     if "--hip" in argv:
         import addingdisparityfiltering_amd as xi
 
