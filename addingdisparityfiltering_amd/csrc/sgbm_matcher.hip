@@ -132,12 +132,28 @@ __global__ void __launch_bounds__(256) sgbm_cost_kernel(CostArgs a)
     const uint32_t* rec2 = a.rec2 + (size_t)img * a.rec_pair;
     int16_t* C = a.C + (size_t)img * a.vol;
     const int dl = wave_active ? d0 : dbase;                  // idle waves walk along (they share the barriers and the stores)
-    int ring[BS][DD], csum[DD];
+    // Round 4: TWO disparities share a register from the pixel cost on (low / high half) wherever the block sum fits 16
+    // bits -- a pixel cost is at most 189 per channel (derivative distance <= 2 * 63, intensity distance <= 255 / 4) --
+    // so the window shifts, the running sums and the clamp run once per pair: about a third fewer vector instructions
+    // in a kernel that is bound by issuing them.  (Sums of halves never carry: every intermediate stays below 2^16, and
+    // the ring entry is subtracted from the running sum BEFORE the new one is added.)
+    constexpr bool PACK = BS * BS * CN * 189 < 65536;
+    int ring[PACK ? 1 : BS][PACK ? 1 : DD], csum[PACK ? 1 : DD];
+    uint32_t ring2[PACK ? BS : 1][PACK ? DD / 2 : 1], csum2[PACK ? DD / 2 : 1];
+    if constexpr (PACK) {
 #pragma unroll
-    for (int dd = 0; dd < DD; dd++) {
-        csum[dd] = 0;
+        for (int j = 0; j < DD / 2; j++) {
+            csum2[j] = 0;
 #pragma unroll
-        for (int k = 0; k < BS; k++) ring[k][dd] = 0;
+            for (int k = 0; k < BS; k++) ring2[k][j] = 0;
+        }
+    } else {
+#pragma unroll
+        for (int dd = 0; dd < DD; dd++) {
+            csum[dd] = 0;
+#pragma unroll
+            for (int k = 0; k < BS; k++) ring[k][dd] = 0;
+        }
     }
     // write-out: 16 bytes per thread, TD/8 threads per column => every store instruction covers whole contiguous pieces
     constexpr int TPC = TD / 8;                               // threads per column
@@ -154,9 +170,9 @@ __global__ void __launch_bounds__(256) sgbm_cost_kernel(CostArgs a)
                 Rec u[CN];
 #pragma unroll
                 for (int c = 0; c < CN; c++) u[c] = Rec{pu[c * 3], pu[c * 3 + 1], pu[c * 3 + 2]};
-                short res[DD];
-#pragma unroll
-                for (int dd = 0; dd < DD; dd++) {
+                short res[PACK ? 1 : DD];
+                uint32_t res2[PACK ? DD / 2 : 1];
+                auto pixel_cost = [&](int dd) -> uint32_t {
                     us2 acc = {0, 0};
 #pragma unroll
                     for (int c = 0; c < CN; c++) {
@@ -164,7 +180,28 @@ __global__ void __launch_bounds__(256) sgbm_cost_kernel(CostArgs a)
                         const Rec v = {q[0], q[1], q[2]};
                         acc += bt_pair(u[c], v);
                     }
-                    const int pix = (int)acc.x + (int)acc.y;
+                    return (uint32_t)acc.x + (uint32_t)acc.y;
+                };
+                if constexpr (PACK) {
+#pragma unroll
+                    for (int j = 0; j < DD / 2; j++) {
+                        const uint32_t pp = pixel_cost(2 * j) | (pixel_cost(2 * j + 1) << 16);
+                        uint32_t hs = pp, tl = pp, tr = pp;
+#pragma unroll
+                        for (int k = 0; k < R; k++) {               // neighbours' pixel costs, one more column per shift
+                            tl = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)tl, 0x138, 0xf, 0xf, true);   // wave_shr:1, 0 past the wave's end
+                            tr = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)tr, 0x130, 0xf, 0xf, true);   // wave_shl:1
+                            hs += tl + tr;
+                        }
+                        csum2[j] = (csum2[j] - ring2[s][j]) + hs;
+                        ring2[s][j] = hs;
+                        const us2 cl = __builtin_elementwise_min(__builtin_bit_cast(us2, csum2[j]), (us2){(unsigned short)SG_MAX_COST, (unsigned short)SG_MAX_COST});
+                        res2[j] = __builtin_bit_cast(uint32_t, cl);
+                    }
+                } else {
+#pragma unroll
+                for (int dd = 0; dd < DD; dd++) {
+                    const int pix = (int)pixel_cost(dd);
                     int hs = pix, tl = pix, tr = pix;
 #pragma unroll
                     for (int k = 0; k < R; k++) {                   // neighbours' pixel costs, one more column per shift
@@ -176,16 +213,22 @@ __global__ void __launch_bounds__(256) sgbm_cost_kernel(CostArgs a)
                     ring[s][dd] = hs;
                     res[dd] = (short)min(csum[dd], SG_MAX_COST);
                 }
+                }
                 if (n >= BS - 1) {                               // block-uniform: a row of results goes out through LDS
                     typedef short v8s __attribute__((ext_vector_type(8)));
                     int16_t* tl_ = tile[n & 1];
                     if (wave_active) {
 #pragma unroll
                         for (int h = 0; h < DD / 8; h++) {
-                            v8s q;
+                            if constexpr (PACK) {
+                                typedef uint32_t v4u __attribute__((ext_vector_type(4)));
+                                *reinterpret_cast<v4u*>(tl_ + lane * TP + wv * DD + h * 8) = v4u{res2[4 * h], res2[4 * h + 1], res2[4 * h + 2], res2[4 * h + 3]};
+                            } else {
+                                v8s q;
 #pragma unroll
-                            for (int k = 0; k < 8; k++) q[k] = res[h * 8 + k];
-                            *reinterpret_cast<v8s*>(tl_ + lane * TP + wv * DD + h * 8) = q;
+                                for (int k = 0; k < 8; k++) q[k] = res[h * 8 + k];
+                                *reinterpret_cast<v8s*>(tl_ + lane * TP + wv * DD + h * 8) = q;
+                            }
                         }
                     }
                     __syncthreads();
