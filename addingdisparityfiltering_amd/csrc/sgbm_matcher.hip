@@ -21,7 +21,7 @@
 //                         butterfly + 4 readlanes.  TOP writes the volume S, LEFT adds to it, RIGHT adds, picks the
 //                         winner and fits the sub-pixel parabola (stereo_binary_sgbm.cpp:286-301, 419-446, 519-596)
 //   sgbm_fill_kernel / sgbm_median_kernel   invalid value everywhere first; 3x3 median of the CV_16S map last
-// HBM: C and S volumes of H x width1 x D int16 each (4K, 256 disparities: 4 GB each, per image in flight).
+// HBM: C, S and L2 volumes of H x width1 x D int16 each (4K, 256 disparities: 4 GB each, per image in flight).
 #include "adf_internal.h"
 #include "../../include/adf_wls.h"
 
@@ -252,10 +252,14 @@ __global__ void __launch_bounds__(256) sgbm_cost_kernel(CostArgs a)
 // ---------------------------------------------------------------------------------------------------------------
 // DIR_TOP: first path, writes S; DIR_ADD: any direction of travel (dx, dy) in {-1,0,1}^2, adds to S; DIR_RIGHT: the last
 // path (from the right), adds, picks the winner
-enum { DIR_TOP = 0, DIR_ADD = 1, DIR_RIGHT = 2 };
+// DIR_ADD_OUT (round 4): the LAST accumulating path writes its costs to a volume of its own (L2) instead of adding them into
+// S -- it no longer reads S (8 bytes per pixel and disparity moved instead of 12) -- and DIR_RIGHT, which is bound by
+// vector issue and has bandwidth to spare, reads both and adds them in the accumulation's own order:
+// sat(sat(S + L_last) + L_right).
+enum { DIR_TOP = 0, DIR_ADD = 1, DIR_RIGHT = 2, DIR_ADD_OUT = 3 };
 
 struct PathArgs {
-    const int16_t* C; int16_t* S; size_t vol;
+    const int16_t* C; int16_t* S; int16_t* L2; size_t vol;
     int W, H, D, minD, minX1, w1, P1, P2, ur;
     int16_t* out; ptrdiff_t out_stride, out_pair;   // raw disparity map (elements)
     int dx, dy;                                     // DIR_ADD: direction of travel
@@ -345,6 +349,8 @@ __global__ void __launch_bounds__(256) sgbm_path_kernel(PathArgs a)
     // a lane's DPL disparities are all inside [0, D) or all outside (D is a multiple of 16, DPL divides 16)
     const int16_t* C = a.C + vol0 + (active ? d0 : 0);
     int16_t* S = a.S + vol0 + (active ? d0 : 0);
+    int16_t* L2 = a.L2 + vol0 + (active ? d0 : 0);
+    constexpr bool READS_S = DIR == DIR_ADD || DIR == DIR_RIGHT;
     // element offset of step t
     auto offs = [&](int t) -> size_t {
         return ((size_t)(y0 + t * dy) * a.w1 + (size_t)(x0 + t * dx)) * a.D;
@@ -364,7 +370,10 @@ __global__ void __launch_bounds__(256) sgbm_path_kernel(PathArgs a)
         for (int x = lane; x < a.W; x += 64) { d2p[x] = invalid; d2c[x] = (int16_t)SG_MAX_COST; }   // :449-453
 
     // one step of formula 13 at scanline position t with the operands c (block cost) and s (S so far)
-    auto step = [&](int t, const int (&c)[DPL], const int (&s)[DPL]) {
+    auto step = [&](int t, const int (&c)[DPL], const int (&s_in)[DPL], const int (&l2)[DPL]) {
+        int s[DPL];
+#pragma unroll
+        for (int k = 0; k < DPL; k++) s[k] = DIR == DIR_RIGHT ? sat16i(s_in[k] + l2[k]) : s_in[k];   // the last accumulating path's costs
         const size_t o = offs(t);
         // stereo_binary_sgbm.cpp:419-446: neighbours d-1 / d+1, guards SHRT_MAX outside [0, D)
         const int lm = __builtin_amdgcn_update_dpp(SG_MAX_COST, L[DPL - 1], 0x138, 0xf, 0xf, false);   // wave_shr:1
@@ -383,6 +392,8 @@ __global__ void __launch_bounds__(256) sgbm_path_kernel(PathArgs a)
         minprev = wave_min_i32(lmin);
         if (DIR == DIR_TOP) {
             store_costs<DPL>(S + o, active, Ln);
+        } else if (DIR == DIR_ADD_OUT) {
+            store_costs<DPL>(L2 + o, active, Ln);
         } else {
             int st[DPL];
 #pragma unroll
@@ -431,34 +442,38 @@ __global__ void __launch_bounds__(256) sgbm_path_kernel(PathArgs a)
     // latency).  The pipelined loop has NO branch around a vector-memory operation: with one, the compiler can only
     // wait for every outstanding load at each use, which serialises the ring.
     constexpr int PF = DPL >= 8 ? 4 : 8;
-    int cq[PF][DPL], sq[PF][DPL];
+    int cq[PF][DPL], sq[PF][DPL], lq[DIR == DIR_RIGHT ? PF : 1][DPL];
+#pragma unroll
+    for (int k = 0; k < DPL; k++) lq[0][k] = 0;
 #pragma unroll
     for (int p = 0; p < PF; p++) {
         const int tt = p < nsteps ? p : nsteps - 1;
         load_costs<DPL>(C + offs(tt), cq[p]);
-        if (DIR != DIR_TOP) load_costs<DPL>(S + offs(tt), sq[p]);
+        if (READS_S) load_costs<DPL>(S + offs(tt), sq[p]);
         else {
 #pragma unroll
             for (int k = 0; k < DPL; k++) sq[p][k] = 0;
         }
+        if (DIR == DIR_RIGHT) load_costs<DPL>(L2 + offs(tt), lq[p]);
     }
     int t0 = 0;
     for (; t0 + PF <= nsteps; t0 += PF) {
 #pragma unroll
         for (int p = 0; p < PF; p++) {
             const int t = t0 + p;
-            int c[DPL], s[DPL];
+            int c[DPL], s[DPL], l2[DPL];
 #pragma unroll
-            for (int k = 0; k < DPL; k++) { c[k] = cq[p][k]; s[k] = sq[p][k]; }
+            for (int k = 0; k < DPL; k++) { c[k] = cq[p][k]; s[k] = sq[p][k]; l2[k] = lq[DIR == DIR_RIGHT ? p : 0][k]; }
             const int tt = t + PF < nsteps ? t + PF : nsteps - 1;
             load_costs<DPL>(C + offs(tt), cq[p]);
-            if (DIR != DIR_TOP) load_costs<DPL>(S + offs(tt), sq[p]);
-            step(t, c, s);
+            if (READS_S) load_costs<DPL>(S + offs(tt), sq[p]);
+            if (DIR == DIR_RIGHT) load_costs<DPL>(L2 + offs(tt), lq[p]);
+            step(t, c, s, l2);
         }
     }
 #pragma unroll
     for (int p = 0; p < PF; p++)                              // the last nsteps % PF steps: operands already in the ring
-        if (t0 + p < nsteps) step(t0 + p, cq[p], sq[p]);
+        if (t0 + p < nsteps) step(t0 + p, cq[p], sq[p], lq[DIR == DIR_RIGHT ? p : 0]);
 
     if (DIR == DIR_RIGHT) {                                   // the scanline's results, coalesced
         int16_t* out = a.out + (ptrdiff_t)blockIdx.y * a.out_pair + (ptrdiff_t)line * a.out_stride + a.minX1;
@@ -557,7 +572,9 @@ hipError_t launch_paths(const PathArgs& a0, int mode, int n, hipStream_t st)
     for (int k = 0; k < nadd; k++) {
         a.dx = add[k][0]; a.dy = add[k][1];
         const int nlines = a.dy == 0 ? a.H : (a.dx == 0 ? a.w1 : a.w1 + a.H - 1);
-        hipLaunchKernelGGL((sgbm_path_kernel<DPL, DIR_ADD>), dim3((nlines + 3) / 4, n), dim3(256), 0, st, a);
+        // the last of them writes its own volume (no read-modify-write of S); the winner kernel adds it in
+        if (k == nadd - 1) hipLaunchKernelGGL((sgbm_path_kernel<DPL, DIR_ADD_OUT>), dim3((nlines + 3) / 4, n), dim3(256), 0, st, a);
+        else hipLaunchKernelGGL((sgbm_path_kernel<DPL, DIR_ADD>), dim3((nlines + 3) / 4, n), dim3(256), 0, st, a);
     }
     const size_t lds_out = ((size_t)a.w1 + (a.disp12 < 100000 ? 2 * (size_t)a.W : 0)) * 4 * sizeof(int16_t);
     if (lds_out > 150 * 1024) return hipErrorInvalidValue;
@@ -705,7 +722,7 @@ extern "C" int adf_sgbm_compute_device(adf_sgbm_t* h, int n_pairs,
     const size_t volp = vol_bytes / 2;                                                // int16 elements
     const size_t raw_bytes = up256((size_t)W * H * 2);
     const size_t raw_el = raw_bytes / 2;
-    const size_t per_img = 2 * rec_bytes + 2 * vol_bytes + raw_bytes;
+    const size_t per_img = 2 * rec_bytes + 3 * vol_bytes + raw_bytes;     // C, S and the last accumulating path's own volume
     int chunk = (int)(h->ws_limit / per_img);
     if (chunk < 1) chunk = 1;
     if (chunk > n_pairs) chunk = n_pairs;
@@ -716,7 +733,8 @@ extern "C" int adf_sgbm_compute_device(adf_sgbm_t* h, int n_pairs,
     uint32_t* rec2 = (uint32_t*)(wsb + rec_bytes * chunk);
     int16_t* Cv = (int16_t*)(wsb + 2 * rec_bytes * chunk);
     int16_t* Sv = (int16_t*)(wsb + 2 * rec_bytes * chunk + vol_bytes * chunk);
-    int16_t* raw = (int16_t*)(wsb + 2 * rec_bytes * chunk + 2 * vol_bytes * chunk);
+    int16_t* Lv = (int16_t*)(wsb + 2 * rec_bytes * chunk + 2 * vol_bytes * chunk);
+    int16_t* raw = (int16_t*)(wsb + 2 * rec_bytes * chunk + 3 * vol_bytes * chunk);
 
     for (int first = 0; first < n_pairs; first += chunk) {
         const int n = std::min(chunk, n_pairs - first);
@@ -738,7 +756,7 @@ extern "C" int adf_sgbm_compute_device(adf_sgbm_t* h, int n_pairs,
             if ((size_t)((H + rpb - 1) / rpb) * n > 65535) return sg_fail(ADF_ESIZE, "too many images per call for the cost kernel's grid");
             hipError_t e = cn == 1 ? launch_cost<1>(ca, bs, n, st) : launch_cost<3>(ca, bs, n, st);
             if (e != hipSuccess) return sg_fail(ADF_EHIP, hipGetErrorString(e));
-            PathArgs pa{Cv, Sv, volp, W, H, D, minD, minX1, w1, P1, P2, ur, raw, (ptrdiff_t)W, (ptrdiff_t)raw_el, 0, 0, h->disp12};
+            PathArgs pa{Cv, Sv, Lv, volp, W, H, D, minD, minX1, w1, P1, P2, ur, raw, (ptrdiff_t)W, (ptrdiff_t)raw_el, 0, 0, h->disp12};
             e = D <= 64 ? launch_paths<1>(pa, h->mode, n, st) : D <= 128 ? launch_paths<2>(pa, h->mode, n, st)
               : D <= 256 ? launch_paths<4>(pa, h->mode, n, st) : launch_paths<8>(pa, h->mode, n, st);
             if (e != hipSuccess) return sg_fail(ADF_EHIP, hipGetErrorString(e));
