@@ -171,8 +171,9 @@ def test_one_shot_calls_from_several_threads(adf):
 
 @pytest.mark.gpu
 def test_device_filter_call_captured_into_a_graph(adf):
-    """adf_fgs_filter_device queues kernels only: it can be captured and replayed; the handle's ordering event is left
-    alone once a call has been captured (adf_api.hip: fgs_end), and such a handle is freed, not cached, at destruction."""
+    """adf_fgs_filter_device queues kernels only: it can be captured and replayed; a call that is being captured leaves
+    the handle's ordering event alone (adf_api.hip: fgs_begin / fgs_end), later ordinary calls use it again, and a handle
+    that was ever captured is freed, not cached, at destruction."""
     import torch
 
     dev = torch.device("cuda", 0)
@@ -197,6 +198,21 @@ def test_device_filter_call_captured_into_a_graph(adf):
     graph.replay()
     torch.cuda.synchronize()
     assert torch.equal(dst, want2)
+    # Round 4: the capture state is not latched -- ordinary calls on the captured handle record and wait for
+    # its event again, so two streams sharing the handle stay ordered: a long call on one stream, then a call on another
+    # that overwrites the same planes, must both come out right.
+    sa, sb = torch.cuda.Stream(), torch.cuda.Stream()
+    sa.wait_stream(torch.cuda.current_stream()); sb.wait_stream(torch.cuda.current_stream())
+    s1 = s.flip(1).contiguous()
+    want1 = adf.createFastGlobalSmootherFilter(g, 4000.0, 9.0).filter(s1).clone()
+    torch.cuda.synchronize()
+    for _ in range(4):
+        with torch.cuda.stream(sa):
+            da = f.filter(s1)
+        with torch.cuda.stream(sb):
+            db = f.filter(s)
+        torch.cuda.synchronize()
+        assert torch.equal(da, want1) and torch.equal(db, want2)
     del graph, f
     got = adf.fastGlobalSmootherFilter(g, s, 4000.0, 9.0)      # the library goes on working after the captured handle is gone
     torch.cuda.synchronize()
