@@ -1049,6 +1049,7 @@ extern "C" int adf_wls_filter_scaled_device(adf_wls_t* h, int n_pairs,
         return fail(ADF_ESIZE, "scaled ROI (%d,%d,%d,%d) does not fit the %dx%d view", rhi.x, rhi.y, rhi.width, rhi.height, W, H);
 
     DeviceScope ds(h->device);
+    h->lazy_conf.pending = false;    // (the previous call's low-resolution maps are about to be overwritten or freed)
     const size_t lo = (size_t)dW * dH, hi = (size_t)W * H;
     const Geom ghi = make_geom(W, H, rhi.x, rhi.y, rhi.width, rhi.height);   // the geometry wls_filter_impl will derive
     // Can the first row pass interpolate the maps itself (fgs_wave_h.hip, FUSE_LO)?  Confidence mode on the wave solver,
