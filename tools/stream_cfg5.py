@@ -6,8 +6,9 @@ event pair brackets each call on its stream: what the frame's own kernels took, 
 frames cost it).  Issue modes: "calls" = the C-ABI call per frame from ONE host thread (seven to nine launches issued by the
 host per frame), "threads" = the same with one host thread per handle, and
 "graphs" = the same call captured once per handle into a HIP graph and replayed (one launch per frame; the frame is
-copied into the handle's fixed input buffers first, as a camera driver would).  One frame per K is compared with the
-oracle when `check` is set.
+copied into the handle's fixed input buffers first, as a camera driver would; "graphs_inplace": the producer writes those
+buffers itself, so a frame is one replay + the two timing events; "replay_only": the same without the events, ONE
+runtime call per frame, throughput only).  One frame per K is compared with the oracle when `check` is set.
 
     python tools/stream_cfg5.py [frames]          prints the table (profiles/r04_stream_cfg5.txt)
 bench.py's next_rows leg calls `measure()` (never part of `value`)."""
@@ -49,7 +50,7 @@ def measure(adf, torch, dev, synthetic, frames=256, ks=(1, 2, 4, 8), check=True,
                 for _ in range(2):
                     handles[k].filter(dl[k], view[k], out[k], dr[k], roi)
         torch.cuda.synchronize()
-        if mode == "graphs":
+        if mode in ("graphs", "graphs_inplace", "replay_only"):
             for k in range(K):
                 b = (dl[k].clone(), view[k].clone(), dr[k].clone(), torch.empty((H, W), dtype=torch.int16, device=dev))
                 g = torch.cuda.CUDAGraph()
@@ -60,7 +61,13 @@ def measure(adf, torch, dev, synthetic, frames=256, ks=(1, 2, 4, 8), check=True,
         def issue(i, k):
             s = streams[k]
             with torch.cuda.stream(s):
-                if mode == "graphs":
+                if mode == "replay_only":                    # ... and nobody times the frames: ONE runtime call per frame
+                    gr[k].replay()
+                elif mode == "graphs_inplace":               # the producer writes the handle's input buffers itself: one replay per frame
+                    ev[i][0].record(s)
+                    gr[k].replay()
+                    ev[i][1].record(s)
+                elif mode == "graphs":
                     b = bufs[k]
                     b[0].copy_(dl[i], non_blocking=True); b[1].copy_(view[i], non_blocking=True); b[2].copy_(dr[i], non_blocking=True)
                     ev[i][0].record(s)
@@ -91,11 +98,11 @@ def measure(adf, torch, dev, synthetic, frames=256, ks=(1, 2, 4, 8), check=True,
         t_issue = time.perf_counter() - t0
         torch.cuda.synchronize()
         wall = time.perf_counter() - t0
-        lat = [a.elapsed_time(b) * 1e3 for a, b in ev]       # microseconds
+        lat = [a.elapsed_time(b) * 1e3 for a, b in ev] if mode != "replay_only" else [0.0]       # microseconds
         r = {"sustained_Mpixels_per_s": round(frames * W * H / wall / 1e6, 1), "frames_per_s": round(frames / wall, 1),
              "latency_us_median": round(_percentile(lat, 0.5), 1), "latency_us_p99": round(_percentile(lat, 0.99), 1),
              "host_issue_us_per_frame": round(t_issue / frames * 1e6, 1)}
-        if check:
+        if check and mode not in ("graphs_inplace", "replay_only"):               # (in place every replay filters the handle's own frame k: nothing lands in `out`)
             import oracle
             i = frames - 1 - (K // 2)
             p = oracle.default_params(threads=min(16, os.cpu_count() or 1), sigma_color=1.5, disc_radius=radius)
@@ -114,6 +121,8 @@ def measure(adf, torch, dev, synthetic, frames=256, ks=(1, 2, 4, 8), check=True,
             try:
                 out.zero_()
                 entry["graphs"] = run(K, "graphs")
+                entry["graphs_inplace"] = run(K, "graphs_inplace")
+                entry["replay_only"] = run(K, "replay_only")
             except Exception as e:                           # (a capture the runtime refuses must not cost the table)
                 entry["graphs"] = {"error": "%s: %s" % (type(e).__name__, e)}
         res["by_streams"][str(K)] = entry
@@ -158,10 +167,10 @@ def main():
     for K, e in r["by_streams"].items():
         for mode, v in e.items():
             if "error" in v:
-                print("  %2s        | %-6s | %s" % (K, mode, v["error"]))
+                print("  %2s        | %-14s | %s" % (K, mode, v["error"]))
                 continue
             c = v.get("checked", {})
-            print("  %2s        | %-6s | %15.1f | %8.1f | %10.1f / %-10.1f | %8.1f              | %s / %s" % (
+            print("  %2s        | %-14s | %15.1f | %8.1f | %10.1f / %-10.1f | %8.1f              | %s / %s" % (
                 K, mode, v["sustained_Mpixels_per_s"], v["frames_per_s"], v["latency_us_median"], v["latency_us_p99"],
                 v["host_issue_us_per_frame"], c.get("disparity_max_abs_lsb"), c.get("disparity_mean_abs_lsb")))
     print("# micro-batches (B frames per call, one stream): B | sustained Mpx/s | frames/s | call latency median / p99 (us)")
