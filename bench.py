@@ -669,7 +669,7 @@ def next_rows_leg(adf, torch, dev, synthetic, cfg, W, H, ch, seed, n, radius, ch
         spec = importlib.util.spec_from_file_location("adf_stream_cfg5", os.path.join(ROOT, "tools", "stream_cfg5.py"))
         mod = importlib.util.module_from_spec(spec)
         spec.loader.exec_module(mod)
-        res["config5_stream"] = mod.measure(adf, torch, dev, synthetic, frames=256, check=check)
+        res["config5_stream"] = mod.measure(adf, torch, dev, synthetic, frames=1024, check=check)
     except Exception as e:
         res["config5_stream"] = {"error": "%s: %s" % (type(e).__name__, e)}
     res["note"] = "SURVEY 8(f) rows N1 / N2 on the final kernels, and config 5 one frame per call; not part of `value`"

@@ -28,7 +28,7 @@ def _percentile(v, q):
     return v[min(len(v) - 1, int(round(q * (len(v) - 1))))]
 
 
-def measure(adf, torch, dev, synthetic, frames=256, ks=(1, 2, 4, 8), check=True, graphs=True):
+def measure(adf, torch, dev, synthetic, frames=256, ks=(1, 2, 4, 8), check=True, graphs=True, reps=3):
     cfg = synthetic.CONFIGS[5]
     W, H, roi, ch, radius = cfg["W"], cfg["H"], cfg["roi"], cfg["channels"], cfg["radius"]
     view, dl, dr = synthetic.make_artificial_batch_torch(frames, W, H, ch, synthetic.seed_for(5, 0), cfg["rect_disparity"], dev)
@@ -112,17 +112,25 @@ def measure(adf, torch, dev, synthetic, frames=256, ks=(1, 2, 4, 8), check=True,
         del handles, gr, bufs
         return r
 
+    def run3(K, mode):
+        # the host's issue rate bounds most of these figures and jitters from run to run: three runs, the median one
+        # reported, the best rate beside it
+        rs = sorted((run(K, mode) for _ in range(reps)), key=lambda r: r["sustained_Mpixels_per_s"])
+        r = rs[len(rs) // 2]
+        r["best_of_%d_Mpixels_per_s" % reps] = rs[-1]["sustained_Mpixels_per_s"]
+        return r
+
     for K in ks:
-        entry = {"calls": run(K, "calls")}
+        entry = {"calls": run3(K, "calls")}
         if K > 1:
             out.zero_()
-            entry["threads"] = run(K, "threads")
+            entry["threads"] = run3(K, "threads")
         if graphs:
             try:
                 out.zero_()
-                entry["graphs"] = run(K, "graphs")
-                entry["graphs_inplace"] = run(K, "graphs_inplace")
-                entry["replay_only"] = run(K, "replay_only")
+                entry["graphs"] = run3(K, "graphs")
+                entry["graphs_inplace"] = run3(K, "graphs_inplace")
+                entry["replay_only"] = run3(K, "replay_only")
             except Exception as e:                           # (a capture the runtime refuses must not cost the table)
                 entry["graphs"] = {"error": "%s: %s" % (type(e).__name__, e)}
         res["by_streams"][str(K)] = entry
@@ -163,16 +171,18 @@ def main():
     dev = torch.device("cuda:0")
     r = measure(adf, torch, dev, synthetic, frames)
     print("# config 5 as a stream: %d frames of %s" % (r["frames"], r["frame"]))
-    print("# K streams | mode   | sustained Mpx/s | frames/s | latency median / p99 (us) | host issue (us/frame) | checked (max / mean LSB)")
+    print("# K streams | mode           | sustained Mpx/s: median of 3 runs (best) | frames/s | latency median / p99 (us) | host issue (us/frame) | checked (max / mean LSB)")
     for K, e in r["by_streams"].items():
         for mode, v in e.items():
             if "error" in v:
                 print("  %2s        | %-14s | %s" % (K, mode, v["error"]))
                 continue
             c = v.get("checked", {})
-            print("  %2s        | %-14s | %15.1f | %8.1f | %10.1f / %-10.1f | %8.1f              | %s / %s" % (
-                K, mode, v["sustained_Mpixels_per_s"], v["frames_per_s"], v["latency_us_median"], v["latency_us_p99"],
-                v["host_issue_us_per_frame"], c.get("disparity_max_abs_lsb"), c.get("disparity_mean_abs_lsb")))
+            best = [v[k] for k in v if k.startswith("best_of_")]
+            print("  %2s        | %-14s | %9.1f (%7.1f) | %8.1f | %10.1f / %-10.1f | %8.1f              | %s / %s" % (
+                K, mode, v["sustained_Mpixels_per_s"], best[0] if best else v["sustained_Mpixels_per_s"], v["frames_per_s"],
+                v["latency_us_median"], v["latency_us_p99"], v["host_issue_us_per_frame"], c.get("disparity_max_abs_lsb"),
+                c.get("disparity_mean_abs_lsb")))
     print("# micro-batches (B frames per call, one stream): B | sustained Mpx/s | frames/s | call latency median / p99 (us)")
     for B, v in r["micro_batches"].items():
         print("  %3s | %10.1f | %9.1f | %8.1f / %.1f" % (B, v["sustained_Mpixels_per_s"], v["frames_per_s"], v["call_latency_us_median"], v["call_latency_us_p99"]))
