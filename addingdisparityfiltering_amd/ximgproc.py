@@ -44,6 +44,11 @@ def _as_rect(roi):
     return Rect(int(x), int(y), int(w), int(h))
 
 
+_ITEMSIZE = {np.int16: 2, np.uint8: 1, np.float32: 4}
+_TORCH_DTYPE = {np.int16: torch.int16, np.uint8: torch.uint8, np.float32: torch.float32} if torch is not None else {}
+_raw_stream = getattr(getattr(torch, "_C", None), "_cuda_getCurrentRawStream", None) if torch is not None else None
+
+
 class _Image:
     """Pointer + strides of a (N,)H,W(,C) image held by numpy or torch."""
 
@@ -53,14 +58,12 @@ class _Image:
             if not arr.is_cuda:
                 arr = arr.cpu().numpy()
             else:
-                want = {np.int16: torch.int16, np.uint8: torch.uint8, np.float32: torch.float32}[dtype_np]
-                if arr.dtype != want:
-                    raise AdfError(_lib.ADF_EBADARG, "%s must have dtype %s" % (what, want))
+                if arr.dtype != _TORCH_DTYPE[dtype_np]:
+                    raise AdfError(_lib.ADF_EBADARG, "%s must have dtype %s" % (what, _TORCH_DTYPE[dtype_np]))
                 self.device = True
-                shape, strides = tuple(arr.shape), tuple(s * arr.element_size() for s in arr.stride())
+                isz = _ITEMSIZE[dtype_np]
                 self.ptr = arr.data_ptr()
-                self.keep = arr
-                self._finish(shape, strides, np.dtype(dtype_np).itemsize, what, batched, allow_channels)
+                self._finish(arr.shape, [q * isz for q in arr.stride()], isz, what, batched, allow_channels)
                 return
         a = np.asarray(arr)
         if a.dtype != np.dtype(dtype_np):
@@ -71,24 +74,23 @@ class _Image:
         self._finish(a.shape, a.strides, a.itemsize, what, batched, allow_channels)
 
     def _finish(self, shape, strides, itemsize, what, batched, allow_channels):
-        shape, strides = list(shape), list(strides)
-        nd = len(shape) - (1 if batched else 0)
-        if nd == 2:
-            shape.append(1)
-            strides.append(itemsize)
-        elif nd != 3:
+        # (this runs four times per filter call: no list surgery)
+        nd = len(shape)
+        k = 1 if batched else 0
+        if nd - k == 2:
+            self.c, sc, sx = 1, itemsize, strides[k + 1]
+        elif nd - k == 3:
+            self.c, sc, sx = shape[k + 2], strides[k + 2], strides[k + 1]
+        else:
             raise AdfError(_lib.ADF_EBADARG, "%s has an unsupported shape %s" % (what, tuple(shape)))
-        if not batched:
-            shape.insert(0, 1)
-            strides.insert(0, 0)
-        self.n, self.h, self.w, self.c = shape
+        self.n, self.pair_stride = (shape[0], strides[0]) if batched else (1, 0)
+        self.h, self.w, self.stride = shape[k], shape[k + 1], strides[k]
         if self.n < 1 or self.h < 1 or self.w < 1:
             raise AdfError(_lib.ADF_EBADARG, "%s is empty" % what)
         if self.c not in allow_channels:
             raise AdfError(_lib.ADF_EBADARG, "%s must have %s channel(s)" % (what, " or ".join(map(str, allow_channels))))
-        if strides[3] != itemsize or strides[2] != itemsize * self.c:
+        if sc != itemsize or sx != itemsize * self.c:
             raise AdfError(_lib.ADF_ESIZE, "%s rows must be dense (channel-interleaved, unit pixel stride)" % what)
-        self.pair_stride, self.stride = strides[0], strides[1]
 
 
 def _out_like(img, batched, dtype_np):
@@ -101,19 +103,28 @@ def _out_like(img, batched, dtype_np):
 
 def _stream_of(img):
     if img.device:
-        return C.c_void_p(torch.cuda.current_stream(img.keep.device).cuda_stream)
+        dev = img.keep.device
+        if _raw_stream is not None and dev.index is not None:      # the raw handle of torch's current stream, without a Stream object
+            return _raw_stream(dev.index)
+        return torch.cuda.current_stream(dev).cuda_stream
     return None
 
 
-def _check_device(getter, handle, imgs, what):
-    """A handle's workspace lives on the device that was current when it was created (include/adf_wls.h):
-    tensors of another GPU would pair it with foreign pointers and a foreign stream."""
+def _handle_device(getter, handle):
     dev = C.c_int(-1)
     _lib.check(getter(handle, C.byref(dev)))
+    return dev.value
+
+
+def _check_device(getter, handle, imgs, what, dev=None):
+    """A handle's workspace lives on the device that was current when it was created (include/adf_wls.h):
+    tensors of another GPU would pair it with foreign pointers and a foreign stream."""
+    if dev is None:
+        dev = _handle_device(getter, handle)
     for im in imgs:
-        if im is not None and im.device and im.keep.device.index != dev.value:
+        if im is not None and im.device and im.keep.device.index != dev:
             raise AdfError(_lib.ADF_EBADARG, "%s lives on cuda:%d; tensors on cuda:%s cannot be passed to it "
-                                             "(create one handle per GPU)" % (what, dev.value, im.keep.device.index))
+                                             "(create one handle per GPU)" % (what, dev, im.keep.device.index))
 
 
 class DisparityFilter:
@@ -134,6 +145,7 @@ class DisparityWLSFilter(DisparityFilter):
                                              right_offset, top_offset, bottom_offset, min_disp))
         self._use_confidence = bool(use_confidence)
         self._last = None  # (batched, device, example image) of the last filter call
+        self._dev = _handle_device(_lib.lib().adf_wls_get_device, self._h)   # fixed at creation
 
     def __del__(self):
         h, self._h = getattr(self, "_h", None), None
@@ -231,22 +243,23 @@ class DisparityWLSFilter(DisparityFilter):
                 raise AdfError(_lib.ADF_ESIZE, "left and right disparity maps differ in size")  # DF.cpp:263-264
         elif self._use_confidence:
             raise AdfError(_lib.ADF_EBADARG, "disparity_map_right is required with use_confidence")  # DF.cpp:262
-        imgs = [dl, gv] + ([dr] if dr else [])
-        if len({im.device for im in imgs}) != 1:
+        if gv.device != dl.device or (dr is not None and dr.device != dl.device):
             raise AdfError(_lib.ADF_EBADARG, "inputs must all be numpy arrays or all be CUDA tensors")
         if filtered_disparity_map is None:
             filtered_disparity_map = _out_like(gv, batched, np.int16)
         out = _Image(filtered_disparity_map, np.int16, "filtered_disparity_map", batched)
         if (out.n, out.h, out.w) != (gv.n, gv.h, gv.w) or out.device != dl.device:               # DF.cpp:252,282
             raise AdfError(_lib.ADF_ESIZE, "filtered_disparity_map has the wrong size or placement")
-        _check_device(_lib.lib().adf_wls_get_device, self._h, imgs + [out], "this DisparityWLSFilter")
+        if dl.device:
+            _check_device(None, self._h, (dl, gv, dr, out), "this DisparityWLSFilter", self._dev)
         roi = _as_rect(ROI)
-        args = [self._h, dl.n,
-                C.c_void_p(dl.ptr), dl.stride, dl.pair_stride, dl.w, dl.h,
-                C.c_void_p(gv.ptr), gv.stride, gv.pair_stride, gv.c, gv.w, gv.h,
-                C.c_void_p(out.ptr), out.stride, out.pair_stride,
-                C.c_void_p(dr.ptr) if dr else None, dr.stride if dr else 0, dr.pair_stride if dr else 0,
-                C.byref(roi) if roi is not None else None]
+        # (pointers go as plain integers: the prototypes in _lib.py say void*)
+        args = (self._h, dl.n,
+                dl.ptr, dl.stride, dl.pair_stride, dl.w, dl.h,
+                gv.ptr, gv.stride, gv.pair_stride, gv.c, gv.w, gv.h,
+                out.ptr, out.stride, out.pair_stride,
+                dr.ptr if dr else None, dr.stride if dr else 0, dr.pair_stride if dr else 0,
+                C.byref(roi) if roi is not None else None)
         if dl.device:
             _lib.check(_lib.lib().adf_wls_filter_scaled_device(*args, _stream_of(dl)))
         else:
