@@ -672,8 +672,37 @@ def next_rows_leg(adf, torch, dev, synthetic, cfg, W, H, ch, seed, n, radius, ch
         res["config5_stream"] = mod.measure(adf, torch, dev, synthetic, frames=1024, check=check)
     except Exception as e:
         res["config5_stream"] = {"error": "%s: %s" % (type(e).__name__, e)}
+    # ... and issued from C++ through the C-ABI (tools/stream_cfg5.cpp, built by __graft_entry__.build()): a child process,
+    # with HIP's default hardware-queue count and with one queue per stream
+    res["config5_stream_cpp"] = config5_stream_cpp()
     res["note"] = "SURVEY 8(f) rows N1 / N2 on the final kernels, and config 5 one frame per call; not part of `value`"
     return res
+
+
+def config5_stream_cpp(frames=1024):
+    import subprocess
+    exe = os.path.join(ROOT, "tools", "stream_cfg5_cpp")
+    if not os.path.exists(exe):
+        return {"skipped": "tools/stream_cfg5_cpp is not built (python -c 'import __graft_entry__ as g; g.build()')"}
+    out = {"frames": frames, "columns": "sustained Mpixels/s (best of 3), frames/s, host issue us/frame, wall us/frame",
+           "note": "one frame per adf_wls_filter_device call from ONE C++ host thread, K handles on K streams; never part of `value`"}
+    for label, extra in (("default_hw_queues", {}), ("GPU_MAX_HW_QUEUES=6", {"GPU_MAX_HW_QUEUES": "6"})):
+        env = dict(os.environ); env.update(extra)
+        try:
+            p = subprocess.run([exe, str(frames)], env=env, capture_output=True, text=True, timeout=120)
+        except Exception as e:
+            out[label] = {"error": "%s: %s" % (type(e).__name__, e)}
+            continue
+        if p.returncode != 0:
+            out[label] = {"error": "exit code %d: %s" % (p.returncode, (p.stderr or p.stdout)[-300:])}
+            continue
+        rows = {}
+        for ln in p.stdout.splitlines():
+            f = [q.strip() for q in ln.split("|")]
+            if len(f) == 6 and f[0].isdigit():
+                rows["K=%s %s" % (f[0], f[1])] = [float(f[2]), float(f[3]), float(f[4]), float(f[5])]
+        out[label] = rows
+    return out
 
 
 def natural_guide_leg(adf, torch, dev, dl, dr, roi, radius, ch, n, solver, check):
