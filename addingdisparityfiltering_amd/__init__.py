@@ -13,6 +13,7 @@ from .ximgproc import (  # noqa: F401
     PATH_FUSED_FIRST_PASS,
     PATH_MERGED_PREP,
     PATH_SCALED_FUSED,
+    PATH_SCALED_HALF,
     SOLVER_EXACT,
     SOLVER_WAVE,
     StereoBM,

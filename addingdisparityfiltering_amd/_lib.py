@@ -12,7 +12,7 @@ LIB_PATH = os.environ.get("ADF_WLS_LIB") or os.path.join(_HERE, "libadf_wls.so")
 
 ADF_OK, ADF_EBADARG, ADF_ESIZE, ADF_EHIP, ADF_ENOMEM, ADF_ENODEV = range(6)
 SOLVER_EXACT, SOLVER_WAVE = 0, 1
-PATH_CONF_BAND, PATH_FUSED_FIRST_PASS, PATH_MERGED_PREP, PATH_SCALED_FUSED = 1, 2, 4, 8    # adf_wls_get_last_path bits (include/adf_wls.h)
+PATH_CONF_BAND, PATH_FUSED_FIRST_PASS, PATH_MERGED_PREP, PATH_SCALED_FUSED, PATH_SCALED_HALF = 1, 2, 4, 8, 16    # adf_wls_get_last_path bits (include/adf_wls.h)
 DEPTH_8U, DEPTH_16S, DEPTH_32F = 0, 3, 5
 
 

@@ -420,7 +420,7 @@ static int run_passes_wave(const Geom& g, const SolvePlanes& p, int n_rhs, float
             h.lo_w = fuse_first->lo_w; h.lo_h = fuse_first->lo_h; h.hi_x0 = fuse_first->hi_x0; h.hi_y0 = fuse_first->hi_y0;
             h.lo_scale_x = fuse_first->lo_scale_x; h.lo_scale_y = fuse_first->lo_scale_y; h.lo_post_scale = fuse_first->lo_post_scale;
             h.lo_zero_outside = fuse_first->lo_zero_outside; h.lo_vx0 = fuse_first->lo_vx0; h.lo_vy0 = fuse_first->lo_vy0;
-            h.lo_vx1 = fuse_first->lo_vx1; h.lo_vy1 = fuse_first->lo_vy1; h.lo_taps = fuse_first->lo_taps;
+            h.lo_vx1 = fuse_first->lo_vx1; h.lo_vy1 = fuse_first->lo_vy1; h.lo_taps = fuse_first->lo_taps; h.lo_half = fuse_first->lo_half;
         }
         {
             // C + conf + dL read, U0/U1 written (low-resolution maps: their bytes per view pixel, each row counted once)
@@ -497,6 +497,7 @@ struct adf_wls {
         bool pending = false;
         const float* clo = nullptr; int dW = 0, dH = 0; adf_rect rlo{0, 0, 0, 0}; Geom ghi{}; bool band_map = false; int n_pairs = 0;
     } lazy_conf;
+    bool scaled_half = true; // ADF_LO_HALF=0: never the half-width form of the fused low-resolution prologue (A/B, tests)
     bool scaled_fuse = true; // ADF_SCALED_FUSE=0: the down-scaled path through the two resize kernels (A/B measurements)
     bool conf_band = true;   // ADF_CONF_BAND=0: the two-kernel confidence stage (A/B measurements)
     bool merge_small = true; // ADF_MERGE_SMALL=0: never the merged preparation launch (A/B measurements)
@@ -532,6 +533,7 @@ extern "C" int adf_wls_create(adf_wls_t** out, int use_confidence, int l, int r,
     if (const char* e = getenv("ADF_NO_OVERLAP")) h->overlap = atoi(e) == 0;   // measurement knob
     if (const char* e = getenv("ADF_CONF_BAND")) h->conf_band = atoi(e) != 0;    // measurement knob
     if (const char* e = getenv("ADF_SCALED_FUSE")) h->scaled_fuse = atoi(e) != 0;  // measurement knob
+    if (const char* e = getenv("ADF_LO_HALF")) h->scaled_half = atoi(e) != 0;
     if (const char* e = getenv("ADF_MERGE_SMALL")) h->merge_small = atoi(e) != 0;   // measurement knob
     if (const char* e = getenv("ADF_CONF_LDS_FLOOR_KB")) h->conf_lds_floor = (size_t)atoi(e) * 1024;
     *out = h;
@@ -793,6 +795,7 @@ static int wls_filter_impl(adf_wls_t* h, int n_pairs,
                 if (lo_fused) {
                     // the first row pass taps the low-resolution maps itself: no resize launch, no view-sized planes
                     h->last_path |= ADF_PATH_SCALED_FUSED;
+                    if (wave_hpass_lo_half(fuse)) h->last_path |= ADF_PATH_SCALED_HALF;
                     if (first == 0) {
                         if (stream_is_capturing(st)) {
                             // a call captured into a graph is replayed without this host code: the view-sized confidence
@@ -926,7 +929,7 @@ static void scaled_lo_args(const ScaledStage& s, int first, const Geom& g, WaveP
     if (scaled_band_map(s)) {
         f.lo_zero_outside = 1; f.lo_vx0 = s.rlo.x; f.lo_vy0 = s.rlo.y; f.lo_vx1 = s.rlo.x + s.rlo.width; f.lo_vy1 = s.rlo.y + s.rlo.height;
     }
-    f.len = g.rw; f.lo_taps = s.taps;
+    f.len = g.rw; f.lo_taps = s.taps; f.lo_half = s.h->scaled_half ? 1 : 0;
 }
 
 static bool scaled_fuse_lo(const ScaledStage& s, int first, const Geom& g, WavePassArgs& fuse)

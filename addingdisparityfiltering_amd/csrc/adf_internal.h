@@ -172,6 +172,7 @@ struct WavePassArgs {
     int lo_w, lo_h, hi_x0, hi_y0;
     double lo_scale_x, lo_scale_y; float lo_post_scale;
     int lo_zero_outside, lo_vx0, lo_vy0, lo_vx1, lo_vy1;
+    int lo_half;      // 0: never the half-width form of the low-resolution prologue (ADF_LO_HALF=0: A/B and test knob)
     float* lo_taps;   // scratch, 4*ceil(len/4) floats, 16-byte aligned: the launcher fills it with the columns' taps (s0 + fx)
     void* out; ptrdiff_t out_stride, out_pair_stride;
     int out_x0, out_y0, out_cn, out_c;
@@ -208,6 +209,7 @@ hipError_t launch_wave_vpass(const WavePassArgs& a, int n_rhs, int epilogue, int
 int wave_max_row_len();
 bool wave_hpass_can_fuse(const WavePassArgs& a);
 bool wave_hpass_can_fuse_lo(const WavePassArgs& a);   // the low-resolution form: scale / span limits of the LDS staging
+bool wave_hpass_lo_half(const WavePassArgs& a);      // ... in its half-width form (fgs_wave_h.hip, FUSE_LO_HALF)?
 int wave_max_col_len();
 // largest depth-discontinuity radius the tile kernel supports (LDS bound)
 int max_disc_radius();

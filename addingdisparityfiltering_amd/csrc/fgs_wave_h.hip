@@ -40,7 +40,11 @@ using namespace wave;
 // disparity) are staged in the wave's LDS buffer, coalesced, one half of the row's columns at a time, and every lane
 // interpolates its own columns from there with the exact tap arithmetic of resize_kernels.hip.  The two view-sized
 // planes the resize kernels wrote (6 B/px) and this pass read back (6 B/px) never exist.
-constexpr int FUSE_NONE = 0, FUSE_VIEW = 1, FUSE_LO = 2;
+// FUSE_LO_HALF: FUSE_LO for maps of exactly half the view's width (the sample's default) on a ROI that starts on an even
+// column >= 2: the four columns of a float4 group then share FOUR consecutive source elements whatever the lane -- columns
+// 2m, 2m+1, 2m+2, 2m+3 tap (m-1, m), (m, m+1), (m, m+1), (m+1, m+2) -- so the group makes three LDS reads instead of eight
+// and decodes one tap position instead of four.  Same operands, same arithmetic: bit-identical to FUSE_LO (tests).
+constexpr int FUSE_NONE = 0, FUSE_VIEW = 1, FUSE_LO = 2, FUSE_LO_HALF = 3;
 
 // cv::resize's INTER_LINEAR tap of destination index d: source index s0 (and s0 + 1) with weights (1 - fx, fx);
 // borders clamp with weight (1, 0).  Same operations, same order as resize_linear_kernel / the oracle (host and device).
@@ -75,7 +79,8 @@ __global__ void __launch_bounds__(64 * NW, (M > (NW == 2 ? 40 : ADF_H_TWO_WAVE_M
 {
     static_assert(M % 4 == 0 && M >= 4, "chunk length must be a multiple of 4");
     static_assert(NW == 1 || NW == 2, "one or two wavefronts per row");
-    __shared__ float4 stage_all[NW][FUSED == FUSE_LO ? lo_stage_vec4(M) : M * 16];
+    constexpr bool LO = FUSED == FUSE_LO || FUSED == FUSE_LO_HALF;
+    __shared__ float4 stage_all[NW][LO ? lo_stage_vec4(M) : M * 16];
     __shared__ float xch[NW == 2 ? 5 : 1];              // c in front of chunk 64; GS0, GS1, PS, QS of chunk 64
     __shared__ float red[NW == 2 ? 5 : 1][NW == 2 ? 128 : 1];   // separator rows
     __shared__ float xsol[NW == 2 ? 2 : 1][NW == 2 ? 128 : 1];  // their solutions
@@ -126,7 +131,7 @@ __global__ void __launch_bounds__(64 * NW, (M > (NW == 2 ? 40 : ADF_H_TWO_WAVE_M
         // addresses and park the zero in scratch memory)
         // (idx: float4 of the row-major row; uidx: float4 of this wave's part of the interleaved pair row, 2 * M * 64 floats)
         const int u0 = PAIR ? 2 * v0 : v0;
-        if constexpr (FUSED == FUSE_LO) {
+        if constexpr (LO) {
             typedef float v4f __attribute__((ext_vector_type(4)));
             typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));
             typedef short s8u __attribute__((ext_vector_type(8), aligned(2)));
@@ -291,6 +296,20 @@ __global__ void __launch_bounds__(64 * NW, (M > (NW == 2 ? 40 : ADF_H_TWO_WAVE_M
                     const int idx = v0 + 64 * k + lane_t;
                     // all four columns' staged values first (eight LDS reads in flight), the arithmetic afterwards
                     f4a8 cq[4]; s4a4 dq[4]; float fxs[4];
+                    if constexpr (FUSED == FUSE_LO_HALF) {
+                        typedef short s8a4 __attribute__((ext_vector_type(8), aligned(4)));
+                        // (the group's first column taps m - 1: in range by construction, clamped like the general form)
+                        const int sl0 = min(max((int)tp[k][0] - ss[hh], 0), CROW - 4);
+                        const f4a8 ca = *reinterpret_cast<const f4a8*>(Lf + 2 * sl0), cb = *reinterpret_cast<const f4a8*>(Lf + 2 * sl0 + 4);
+                        const s8a4 da = *reinterpret_cast<const s8a4*>(Ls + 2 * sl0);
+                        cq[0] = f4a8{ca[0], ca[1], ca[2], ca[3]}; dq[0] = s4a4{da[0], da[1], da[2], da[3]};
+                        cq[1] = f4a8{ca[2], ca[3], cb[0], cb[1]}; dq[1] = s4a4{da[2], da[3], da[4], da[5]};
+                        cq[2] = cq[1]; dq[2] = dq[1];
+                        cq[3] = f4a8{cb[0], cb[1], cb[2], cb[3]}; dq[3] = s4a4{da[4], da[5], da[6], da[7]};
+                        // the weights from the table all the same: 0.75 / 0.25, and 0 at the frame's clamped last column
+#pragma unroll
+                        for (int c = 0; c < 4; c++) fxs[c] = __builtin_amdgcn_fractf(tp[k][c]);
+                    } else {
 #pragma unroll
                     for (int c = 0; c < 4; c++) {
                         const float t = tp[k][c];
@@ -298,6 +317,7 @@ __global__ void __launch_bounds__(64 * NW, (M > (NW == 2 ? 40 : ADF_H_TWO_WAVE_M
                         const int sl = min(max((int)t - ss[hh], 0), CROW - 2);          // (in range by construction; the clamp keeps a bug from reading other waves' LDS)
                         cq[c] = *reinterpret_cast<const f4a8*>(Lf + 2 * sl);         // conf: row0[s], row1[s], row0[s+1], row1[s+1]
                         dq[c] = *reinterpret_cast<const s4a4*>(Ls + 2 * sl);         // disparity, the same four
+                    }
                     }
                     float cv[4], dv[4];
 #pragma unroll
@@ -514,7 +534,11 @@ hipError_t launch_h(const WavePassArgs& a, int n_rhs, int n_pairs, hipStream_t s
         if (n_rhs != 2 || !a.lo_taps) return hipErrorInvalidValue;
         const int n = ((a.len + 3) / 4) * 4;
         hipLaunchKernelGGL(lo_tap_table_kernel, dim3((n + 255) / 256), dim3(256), 0, st, a.lo_taps, n, a.len, a.hi_x0, a.lo_scale_x, a.lo_w);
-        hipLaunchKernelGGL((wave_hpass_kernel<M, 2, FUSE_LO, NW>), grid, block, 0, st, a);
+        // maps of exactly half the view's width, ROI on an even column >= 2: the form with shared source elements
+        if (wave_hpass_lo_half(a))
+            hipLaunchKernelGGL((wave_hpass_kernel<M, 2, FUSE_LO_HALF, NW>), grid, block, 0, st, a);
+        else
+            hipLaunchKernelGGL((wave_hpass_kernel<M, 2, FUSE_LO, NW>), grid, block, 0, st, a);
     } else if (a.conf_in) {
         if (n_rhs != 2) return hipErrorInvalidValue;
         hipLaunchKernelGGL((wave_hpass_kernel<M, 2, FUSE_VIEW, NW>), grid, block, 0, st, a);
@@ -550,6 +574,14 @@ bool wave_hpass_can_fuse(const WavePassArgs& a)
     if ((reinterpret_cast<uintptr_t>(a.conf_in) & 15u) != 0) return false;
     if (a.dl_stride % 2 != 0 || a.dl_pair_stride % 2 != 0 || (reinterpret_cast<uintptr_t>(a.dl_in) & 1u) != 0) return false;
     return true;
+}
+
+bool wave_hpass_lo_half(const WavePassArgs& a)
+{
+    if (!(a.lo_conf && a.lo_half && a.lo_scale_x == 0.5 && (a.hi_x0 & 1) == 0 && a.hi_x0 >= 2)) return false;
+    int m, nw;
+    pick_row_bucket(a.len, m, nw);
+    return !(m == 60 && nw == 1);     // (that bucket's half-width form needs five registers more than a lane has: the general form)
 }
 
 // The low-resolution form stages, per wavefront and per half of its columns, the source elements its taps touch plus

@@ -23,7 +23,7 @@ import math
 import numpy as np
 
 from . import _lib
-from ._lib import AdfError, PATH_CONF_BAND, PATH_FUSED_FIRST_PASS, PATH_MERGED_PREP, PATH_SCALED_FUSED, Rect, SOLVER_EXACT, SOLVER_WAVE  # noqa: F401  (re-exported)
+from ._lib import AdfError, PATH_CONF_BAND, PATH_FUSED_FIRST_PASS, PATH_MERGED_PREP, PATH_SCALED_FUSED, PATH_SCALED_HALF, Rect, SOLVER_EXACT, SOLVER_WAVE  # noqa: F401  (re-exported)
 
 try:  # torch is optional plumbing: device memory and streams only
     import torch

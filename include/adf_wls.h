@@ -125,6 +125,8 @@ int adf_wls_get_last_solver(const adf_wls_t* h, int* solver);
 #define ADF_PATH_SCALED_FUSED 8      /* down-scaled call: the first row pass interpolated the low-resolution maps itself
                                         (no resize launch); the view-sized confidence map is produced on demand by
                                         adf_wls_get_confidence_* */
+#define ADF_PATH_SCALED_HALF 16      /* ... in its form for maps of exactly half the view's width on a ROI starting on an even
+                                        column >= 2 (the sample's default): four output columns share four source elements */
 int adf_wls_get_last_path(const adf_wls_t* h, int* path_flags);
 
 /* DisparityFilter::filter (DF.hpp:75, DF.cpp:219-298) on a batch of n_pairs

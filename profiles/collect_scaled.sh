@@ -7,9 +7,12 @@ round=${ADF_ROUND:-r04}
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 out=gpurun_out/${round}_scaled_path.txt
 : > $out
-for fuse in 1 0 1 0; do
-  echo "# ADF_SCALED_FUSE=$fuse" >> $out
-  ADF_SCALED_FUSE=$fuse python3 tools/scaled_time.py 3840 2160 64 2 >> $out 2>&1
+# (fuse half): 1 1 = default (half-width form of the fused prologue: the maps are exactly half the view), 1 0 = its general
+# form (ADF_LO_HALF=0), 0 0 = round 3's resize kernels
+for v in "1 1" "1 0" "0 0" "1 1" "1 0" "0 0"; do
+  set -- $v; fuse=$1; half=$2
+  echo "# ADF_SCALED_FUSE=$fuse ADF_LO_HALF=$half" >> $out
+  ADF_SCALED_FUSE=$fuse ADF_LO_HALF=$half python3 tools/scaled_time.py 3840 2160 64 2 >> $out 2>&1
 done
 for fuse in 1 0; do
   rm -rf gpurun_out/${round}_scaled_stats_$fuse

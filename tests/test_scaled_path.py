@@ -204,6 +204,41 @@ def test_fused_scaled_first_pass_equals_the_resize_kernels(adf, oracle, case):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("case", [
+    # view, maps (exactly half), channels, ROI of the maps, radius, the half-width form expected?
+    ((320, 240), (160, 120), 3, (16, 0, 144, 120), 2, True),       # the sample's shape: ROI to the right edge (clamped last column)
+    ((320, 240), (160, 120), 1, (1, 0, 159, 120), 2, True),        # ROI column 2 of the view: the first even column that qualifies
+    ((320, 240), (160, 120), 3, (0, 0, 160, 120), 2, False),       # ROI from column 0 (clamped first column): the general form
+    ((320, 240), (160, 120), 1, (7, 3, 120, 100), 5, True),        # map ROI x odd -> view ROI x = 14: even
+    ((322, 240), (161, 120), 3, (9, 0, 152, 120), 2, True),        # odd map width, ROI to the right edge
+    ((642, 100), (321, 50), 1, (5, 1, 300, 45), 2, True),          # partial last vector, rows off the edges
+    ((2600, 64), (1300, 32), 1, (40, 0, 1260, 32), 2, True),       # chunk bucket 40
+    ((3840, 136), (1920, 68), 3, (128, 0, 1792, 68), 2, True),     # bucket 56: BASELINE config 3's row length, 3584
+    ((3840, 136), (1920, 68), 3, (2, 0, 1918, 68), 2, False),      # bucket 60: the general form (registers)
+    ((4400, 72), (2200, 36), 1, (20, 0, 2180, 36), 2, True),       # more than 4096 columns: two wavefronts per row
+    ((321, 240), (160, 120), 3, (16, 0, 144, 120), 2, False),      # 160 / 321: not exactly half
+])
+def test_half_width_form_equals_the_general_form(adf, case):
+    """Maps of exactly half the view's width: four output columns share four source elements (FUSE_LO_HALF).  Same
+    operands, same arithmetic as the general low-resolution prologue: bit-identical output, and the path flag says which ran."""
+    (w, h), (mw, mh), ch, roi, radius, expect = case
+    view, dl, dr, _ = _scaled_inputs(w, h, mw, mh, ch, seed=3 * w + mh + radius)
+
+    def run(f):
+        f.setSolver(adf.SOLVER_WAVE); f.setSigmaColor(1.5); f.setDepthDiscontinuityRadius(radius)
+        out = f.filter(dl, view, None, dr, roi)
+        return out, f.getLastPath(), f.getConfidenceMap()
+
+    half, ph, ch_ = _filter_with_env(adf, {"ADF_LO_HALF": "1"}, run)
+    gen, pg, cg = _filter_with_env(adf, {"ADF_LO_HALF": "0"}, run)
+    assert ph & adf.PATH_SCALED_FUSED and pg & adf.PATH_SCALED_FUSED
+    assert bool(ph & adf.PATH_SCALED_HALF) == expect, (ph, expect)
+    assert not (pg & adf.PATH_SCALED_HALF)
+    assert np.array_equal(half, gen)
+    assert np.array_equal(ch_, cg)
+
+
+@pytest.mark.gpu
 def test_fused_scaled_falls_back_beyond_the_staging_reach(adf, oracle):
     """0.7 across: the taps of half a row no longer fit the wave's staging buffer -> the resize kernels run."""
     view, dl, dr, roi = _scaled_inputs(320, 240, 224, 168, 3, seed=9)
