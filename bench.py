@@ -686,10 +686,13 @@ def config5_stream_cpp(frames=1024):
         return {"skipped": "tools/stream_cfg5_cpp is not built (python -c 'import __graft_entry__ as g; g.build()')"}
     out = {"frames": frames, "columns": "sustained Mpixels/s (best of 3), frames/s, host issue us/frame, wall us/frame",
            "note": "one frame per adf_wls_filter_device call from ONE C++ host thread, K handles on K streams; never part of `value`"}
-    for label, extra in (("default_hw_queues", {}), ("GPU_MAX_HW_QUEUES=6", {"GPU_MAX_HW_QUEUES": "6"})):
+    # (HIP maps streams of one priority onto 4 hardware queues by default, and two streams then share one: either raise
+    # the queue count in the environment or spread the streams over the three priority levels)
+    for label, extra, prio in (("default_hw_queues", {}, "0"), ("default_hw_queues_stream_priorities_cycling", {}, "2"),
+                               ("GPU_MAX_HW_QUEUES=6", {"GPU_MAX_HW_QUEUES": "6"}, "0")):
         env = dict(os.environ); env.update(extra)
         try:
-            p = subprocess.run([exe, str(frames)], env=env, capture_output=True, text=True, timeout=120)
+            p = subprocess.run([exe, str(frames), "8", prio], env=env, capture_output=True, text=True, timeout=120)
         except Exception as e:
             out[label] = {"error": "%s: %s" % (type(e).__name__, e)}
             continue

@@ -71,10 +71,11 @@ int main(int argc, char** argv)
     const int with_priority = argc > 3 ? atoi(argv[3]) : 0;
     std::vector<hipStream_t> st(S);
     for (int k = 0; k < S; k++) {
-        if (with_priority) CHECK(hipStreamCreateWithPriority(&st[k], hipStreamNonBlocking, 0));
+        if (with_priority == 2) CHECK(hipStreamCreateWithPriority(&st[k], hipStreamNonBlocking, (k % 3) - 1));   // three priority levels, cycling
+        else if (with_priority) CHECK(hipStreamCreateWithPriority(&st[k], hipStreamNonBlocking, 0));
         else CHECK(hipStreamCreateWithFlags(&st[k], hipStreamNonBlocking));
     }
-    printf("# %d streams created up front (%s)\n", S, with_priority ? "hipStreamCreateWithPriority(.., 0)" : "hipStreamCreateWithFlags");
+    printf("# %d streams created up front (%s)\n", S, with_priority == 2 ? "hipStreamCreateWithPriority, priorities -1 / 0 / 1 cycling" : with_priority ? "hipStreamCreateWithPriority(.., 0)" : "hipStreamCreateWithFlags");
     for (int K : {1, 2, 4, 8}) {
         if (K > S) break;
         std::vector<adf_wls_t*> h(K);
