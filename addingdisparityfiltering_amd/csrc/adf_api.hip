@@ -506,20 +506,23 @@ struct adf_wls {
     // share a queue run one after the other: a side stream of the caller's priority lost the overlap for about one caller
     // stream in four (tools/batch_cpp.cpp: 13.5-13.6 ms per 64 x 4K call instead of 12.8-13.2).  Each priority level has a pool
     // of its own, so the side stream is created on a level the caller's stream is NOT on.  ADF_SIDE_PRIORITY overrides (A/B).
+    static bool null_caller_of(hipStream_t s) { return s == nullptr || s == hipStreamLegacy || s == hipStreamPerThread; }
     int ensure_side(hipStream_t caller)
     {
         if (side) return ADF_OK;
         int least = 0, greatest = 0, prio = 0, cp = 0;
         if (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess) { least = greatest = 0; (void)hipGetLastError(); }
-        if (stream_is_capturing(caller) || hipStreamGetPriority(caller, &cp) != hipSuccess) { cp = 0; (void)hipGetLastError(); }
+        if (null_caller_of(caller) || stream_is_capturing(caller) || hipStreamGetPriority(caller, &cp) != hipSuccess) { cp = 0; (void)hipGetLastError(); }
         prio = (cp != greatest) ? greatest : (greatest < least ? greatest + 1 : greatest);   // the highest level, or the one below it
         // (the NULL stream is the exception: beside a side stream of another level its calls took 13.9-14.0 ms, with one of
         // its own level 12.8-13.0 -- torch's default stream is the NULL stream)
-        if (caller == nullptr || caller == hipStreamPerThread) prio = cp;
-        if (const char* e = getenv("ADF_SIDE_PRIORITY")) prio = atoi(e);
+        const bool null_caller = null_caller_of(caller);
+        const char* e = getenv("ADF_SIDE_PRIORITY");
+        if (e) prio = atoi(e);
         if (prio < greatest) prio = greatest;
         if (prio > least) prio = least;
-        HIP_TRY(hipStreamCreateWithPriority(&side, hipStreamNonBlocking, prio));
+        if (null_caller && !e) HIP_TRY(hipStreamCreateWithFlags(&side, hipStreamNonBlocking));   // the default level, as rounds 1-3 did
+        else HIP_TRY(hipStreamCreateWithPriority(&side, hipStreamNonBlocking, prio));
         HIP_TRY(hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming));
         HIP_TRY(hipEventCreateWithFlags(&ev_join, hipEventDisableTiming));
         return ADF_OK;
